@@ -1,0 +1,136 @@
+/*
+ * shielder_hip.h — C ABI of libshielder_hip, the MI355X (gfx950) proving backend that sits
+ * behind the reference's Rust proving entry points:
+ *
+ *   shielder_circuits::generate_proof(&Params, &ProvingKey, circuit, &[Fr], &mut rng) -> Vec<u8>
+ *       call sites  /root/reference/crates/shielder_bindings/src/circuits/mod.rs:103-111
+ *                   /root/reference/tee/crates/shielder-prover-tee/src/circuits/mod.rs:70-78
+ *                   /root/reference/crates/shielder-account/src/call_data.rs:489-501
+ *   powers_of_tau::read(path, Format) -> Params
+ *                   /root/reference/crates/powers-of-tau/lib.rs:61-74
+ *   Params::{commit, commit_lagrange}  (exercised at lib.rs:247-264)
+ *   poseidon::off_circuit::hash        /root/reference/crates/shielder_bindings/src/hash.rs:17-26
+ *
+ * Conventions:
+ *   - every function returns int32 status (SHP_OK = 0); nothing unwinds across the ABI;
+ *     shp_last_error() returns the message of the calling thread's last failure;
+ *   - Fr / Fq cross as 32 bytes: 4 x uint64 little-endian limbs in MONTGOMERY form
+ *     (R = 2^256), the representation of the reference's SRS files; the 32-byte
+ *     little-endian CANONICAL front-door encoding of
+ *     /root/reference/crates/type-conversions/lib.rs:59-73 is converted with
+ *     shp_fr_from_le32 / shp_fr_to_le32;
+ *   - G1 affine = 64 bytes (x | y, Montgomery), identity = all zero;
+ *   - pointers named d_* are DEVICE pointers (HBM) on the current device, h_* are host
+ *     pointers; `stream` is a hipStream_t passed as void* (NULL = the context's stream);
+ *   - the library never falls back to a CPU implementation: without a usable gfx950
+ *     device every compute entry point fails with SHP_ERR_NO_DEVICE.
+ */
+#ifndef SHIELDER_HIP_H
+#define SHIELDER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    SHP_OK = 0,
+    SHP_ERR_INVALID_ARG = 1,
+    SHP_ERR_NO_DEVICE = 2,
+    SHP_ERR_HIP = 3,
+    SHP_ERR_FORMAT = 4,       /* malformed ptau / RawBytes / plan / non-canonical field element */
+    SHP_ERR_INTERNAL = 5,
+    SHP_ERR_UNSATISFIED = 6   /* witness does not satisfy the circuit (lookup input not in table) */
+};
+
+#define SHP_BASIS_MONOMIAL 0  /* Params::commit          : MSM over g          */
+#define SHP_BASIS_LAGRANGE 1  /* Params::commit_lagrange : MSM over g_lagrange */
+
+typedef struct shp_ctx shp_ctx;   /* one per (process, GPU): streams, workspaces, twiddle tables */
+typedef struct shp_srs shp_srs;   /* device-resident KZG SRS ("Params") */
+typedef struct shp_msm shp_msm;   /* fixed-base MSM plan over one table of bases */
+
+/* ---- library / device ------------------------------------------------------------ */
+const char* shp_last_error(void);
+const char* shp_version(void);
+int32_t shp_device_count(int32_t* out);
+/* Binds the calling process to GPU `device` and builds the context (one process per GPU). */
+int32_t shp_ctx_create(int32_t device, shp_ctx** out);
+int32_t shp_ctx_destroy(shp_ctx* ctx);
+int32_t shp_ctx_sync(shp_ctx* ctx);                       /* wait for the context's stream */
+
+/* plain device-memory helpers so that callers without a HIP runtime binding (cgo, ctypes) can
+ * keep inputs resident in HBM */
+int32_t shp_malloc(shp_ctx* ctx, size_t bytes, void** d_out);
+int32_t shp_free(shp_ctx* ctx, void* d_ptr);
+int32_t shp_upload(shp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int32_t shp_download(shp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+/* ---- field front door (host, no GPU needed) --------------------------------------- */
+/* canonical 32-byte LE -> Montgomery limbs; SHP_ERR_FORMAT if >= r
+ * (type-conversions/lib.rs:59-66 panics there) */
+int32_t shp_fr_from_le32(const uint8_t in[32], uint64_t out[4]);
+int32_t shp_fr_to_le32(const uint64_t in[4], uint8_t out[32]);
+
+/* ---- NTT over Fr  (halo2 EvaluationDomain: best_fft / lagrange_to_coeff / coeff_to_extended;
+ *      conventions pinned by resources/ppot_0080_11_raw and Halo2Verifier.sol:475) ------ */
+/* `batch` polynomials of 2^log_n elements each, contiguous, in place, natural order in and out.
+ * inverse != 0: omega^{-1} and the 1/n scaling (lagrange_to_coeff). */
+int32_t shp_ntt_fr(shp_ctx* ctx, void* d_data, uint32_t log_n, uint32_t batch, int32_t inverse, void* stream);
+/* coeff_to_extended: d_in = batch x 2^k coefficients; d_out = batch x 2^ext_k evaluations on the
+ * zeta-coset (coefficient i scaled by [1, zeta, zeta^2][i mod 3], zero-padded, forward NTT). */
+int32_t shp_coeff_to_extended(shp_ctx* ctx, const void* d_in, void* d_out, uint32_t k, uint32_t ext_k,
+                              uint32_t batch, void* stream);
+/* extended_to_coeff, in place on batch x 2^ext_k values (inverse NTT, then [1, zeta^2, zeta][i mod 3]). */
+int32_t shp_extended_to_coeff(shp_ctx* ctx, void* d_data, uint32_t ext_k, uint32_t batch, void* stream);
+
+/* ---- G1 multi-scalar multiplication (halo2curves best_multiexp behind Params::commit*) --- */
+/* Builds the fixed-base plan over `n` affine bases: the window tables 2^(c*w) * P_i are
+ * precomputed once into HBM (n * ceil(255/c) * 64 bytes), so that one MSM is a single
+ * bucket pass with no doublings.  window_bits = 0 picks c from n. */
+int32_t shp_msm_create(shp_ctx* ctx, const void* h_bases, size_t n, uint32_t window_bits, shp_msm** out);
+int32_t shp_msm_create_dev(shp_ctx* ctx, const void* d_bases, size_t n, uint32_t window_bits, shp_msm** out);
+int32_t shp_msm_destroy(shp_msm* m);
+/* `batch` scalar vectors (each `n_scalars` <= n Fr, contiguous in HBM with stride
+ * `stride_elems` elements) against the same bases -> `batch` affine points (host, 64 B each). */
+int32_t shp_msm_g1(shp_msm* m, const void* d_scalars, size_t n_scalars, size_t stride_elems, uint32_t batch,
+                   void* h_out_affine, void* stream);
+/* bytes of algorithmic HBM traffic and group operations of the last shp_msm_g1 call */
+int32_t shp_msm_last_stats(shp_msm* m, uint64_t* point_adds, uint64_t* bytes);
+
+/* ---- Poseidon2 t=8 (poseidon::off_circuit::hash, generate_t8.py) ---------------------- */
+/* n_hashes independent hashes of `arity` (1..7) inputs each: d_in = n_hashes x arity Fr (row
+ * major), d_out = n_hashes Fr. */
+int32_t shp_poseidon2_t8(shp_ctx* ctx, const void* d_in, size_t n_hashes, uint32_t arity, void* d_out, void* stream);
+/* raw permutation on n_states x 8 Fr, in place */
+int32_t shp_poseidon2_t8_permute(shp_ctx* ctx, void* d_states, size_t n_states, void* stream);
+
+/* ---- SRS ("Params") --------------------------------------------------------------- */
+/* powers_of_tau::read(.., PerpetualPowersOfTau): parses the snarkjs .ptau bytes, derives
+ * g_lagrange on the GPU (group FFT), uploads both tables and builds both MSM plans. */
+int32_t shp_srs_from_ptau(shp_ctx* ctx, const uint8_t* bytes, size_t len, shp_srs** out);
+/* powers_of_tau::read(.., Raw): halo2 ParamsKZG RawBytes (k | g | g_lagrange | g2 | s_g2). */
+int32_t shp_srs_from_halo2_raw(shp_ctx* ctx, const uint8_t* bytes, size_t len, shp_srs** out);
+/* Params from explicit tables (e.g. a synthetic SRS); g2 / s_g2 may be NULL. */
+int32_t shp_srs_from_parts(shp_ctx* ctx, uint32_t k, const void* h_g, const void* h_g_lagrange,
+                           const uint8_t* g2_128, const uint8_t* s_g2_128, shp_srs** out);
+int32_t shp_srs_destroy(shp_srs* srs);
+int32_t shp_srs_k(const shp_srs* srs, uint32_t* k);
+/* copies of the tables / G2 elements back to the host (Params::get_g, g2, s_g2) */
+int32_t shp_srs_get_g(const shp_srs* srs, int32_t basis, void* h_out, size_t n_points);
+int32_t shp_srs_get_g2(const shp_srs* srs, uint8_t g2_128[128], uint8_t s_g2_128[128]);
+/* Params::commit / commit_lagrange on `batch` device-resident polynomials of 2^k Fr each */
+int32_t shp_srs_commit(shp_srs* srs, int32_t basis, const void* d_polys, uint32_t batch, void* h_out_affine,
+                       void* stream);
+
+/* ---- diagnostics ------------------------------------------------------------------- */
+/* sustained Fr Montgomery products per second with every CU busy: the integer-ALU ceiling that
+ * bounds MSM and NTT on this part (DESIGN.md "Rooflines") */
+int32_t shp_diag_fr_mul_rate(shp_ctx* ctx, uint32_t iters, double* muls_per_sec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,238 @@
+"""ctypes binding of libshielder_hip.so (include/shielder_hip.h).
+
+Mirrors the reference's Rust surface for the proving path:
+  Params (powers_of_tau::read, commit, commit_lagrange)   /root/reference/crates/powers-of-tau/lib.rs:61-74, 247-264
+  poseidon::off_circuit::hash                              /root/reference/crates/shielder_bindings/src/hash.rs:17-26
+Field elements are numpy uint64 arrays (..., 4): little-endian Montgomery limbs.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "libshielder_hip.so")
+R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+Q_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+SHP_OK = 0
+BASIS_MONOMIAL, BASIS_LAGRANGE = 0, 1
+
+
+class ShpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libshielder_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_DIR, "csrc", f) for f in os.listdir(os.path.join(_DIR, "csrc"))
+            if f.endswith((".hip", ".cuh", ".hpp", ".inc"))]
+    srcs.append(os.path.join(_DIR, "..", "include", "shielder_hip.h"))
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_DIR, "csrc"), "-j4"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    """The HIP library; raises if it has not been built (there is no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise ShpError(-1, f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "-- the product path has no CPU fallback")
+        _lib = C.CDLL(_SO)
+        _lib.shp_last_error.restype = C.c_char_p
+        _lib.shp_version.restype = C.c_char_p
+    return _lib
+
+
+def _check(rc):
+    if rc != SHP_OK:
+        raise ShpError(rc, lib().shp_last_error().decode())
+
+
+def _vp(x):
+    return C.c_void_p(int(x))
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---------------------------------------------------------------- host field helpers (no GPU)
+def fr_from_le32(b: bytes):
+    out = (C.c_uint64 * 4)()
+    _check(lib().shp_fr_from_le32(C.c_char_p(bytes(b)), out))
+    return np.array(list(out), dtype=np.uint64)
+
+
+def fr_to_le32(limbs) -> bytes:
+    a = (C.c_uint64 * 4)(*[int(v) for v in np.asarray(limbs, dtype=np.uint64).reshape(4)])
+    out = C.create_string_buffer(32)
+    _check(lib().shp_fr_to_le32(a, out))
+    return out.raw
+
+
+def to_device(arr):
+    """numpy uint64 (...,4|8) -> torch int64 CUDA tensor with the same bytes"""
+    import torch
+    a = np.ascontiguousarray(arr, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).cuda()
+
+
+def to_host(t):
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+class Context:
+    """One per (process, GPU): shp_ctx."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _check(lib().shp_ctx_create(C.c_int32(device), C.byref(self.h)))
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().shp_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def sync(self):
+        _check(lib().shp_ctx_sync(self.h))
+
+    def fr_mul_rate(self, iters=4096):
+        out = C.c_double()
+        _check(lib().shp_diag_fr_mul_rate(self.h, C.c_uint32(iters), C.byref(out)))
+        return out.value
+
+    # -- NTT -------------------------------------------------------------------------
+    def ntt(self, t, log_n, batch=1, inverse=False):
+        """in place on a torch int64 CUDA tensor holding batch x 2^log_n Fr"""
+        assert t.is_cuda and t.numel() == batch * (1 << log_n) * 4
+        _check(lib().shp_ntt_fr(self.h, _vp(t.data_ptr()), C.c_uint32(log_n), C.c_uint32(batch),
+                                C.c_int32(1 if inverse else 0), _stream()))
+        return t
+
+    def coeff_to_extended(self, t_in, k, ext_k, batch=1):
+        import torch
+        out = torch.empty(batch * (1 << ext_k) * 4, dtype=torch.int64, device=t_in.device)
+        _check(lib().shp_coeff_to_extended(self.h, _vp(t_in.data_ptr()), _vp(out.data_ptr()), C.c_uint32(k),
+                                           C.c_uint32(ext_k), C.c_uint32(batch), _stream()))
+        return out
+
+    def extended_to_coeff(self, t, ext_k, batch=1):
+        _check(lib().shp_extended_to_coeff(self.h, _vp(t.data_ptr()), C.c_uint32(ext_k), C.c_uint32(batch), _stream()))
+        return t
+
+    # -- Poseidon2 ---------------------------------------------------------------------
+    def poseidon2_hash(self, t_in, n_hashes, arity):
+        import torch
+        out = torch.empty(n_hashes * 4, dtype=torch.int64, device=t_in.device)
+        _check(lib().shp_poseidon2_t8(self.h, _vp(t_in.data_ptr()), C.c_size_t(n_hashes), C.c_uint32(arity),
+                                      _vp(out.data_ptr()), _stream()))
+        return out
+
+    def poseidon2_permute(self, t_states, n_states):
+        _check(lib().shp_poseidon2_t8_permute(self.h, _vp(t_states.data_ptr()), C.c_size_t(n_states), _stream()))
+        return t_states
+
+
+class Msm:
+    """Fixed-base MSM plan (shp_msm)."""
+
+    def __init__(self, ctx: Context, bases, window_bits=0):
+        bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+        self.ctx, self.n = ctx, bases.shape[0]
+        self.h = C.c_void_p()
+        _check(lib().shp_msm_create(ctx.h, bases.ctypes.data_as(C.c_void_p), C.c_size_t(self.n),
+                                    C.c_uint32(window_bits), C.byref(self.h)))
+
+    @classmethod
+    def from_device(cls, ctx: Context, t_bases, n, window_bits=0):
+        self = cls.__new__(cls)
+        self.ctx, self.n = ctx, n
+        self.h = C.c_void_p()
+        _check(lib().shp_msm_create_dev(ctx.h, _vp(t_bases.data_ptr()), C.c_size_t(n), C.c_uint32(window_bits),
+                                        C.byref(self.h)))
+        return self
+
+    def run(self, t_scalars, n_scalars, batch=1, stride=0):
+        out = np.zeros((batch, 8), dtype=np.uint64)
+        _check(lib().shp_msm_g1(self.h, _vp(t_scalars.data_ptr()), C.c_size_t(n_scalars), C.c_size_t(stride),
+                                C.c_uint32(batch), out.ctypes.data_as(C.c_void_p), _stream()))
+        return out
+
+    def stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().shp_msm_last_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self.h:
+            lib().shp_msm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Params:
+    """Device-resident KZG SRS: the reference's `Params` (ParamsKZG<Bn256>)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+        k = C.c_uint32()
+        _check(lib().shp_srs_k(self.h, C.byref(k)))
+        self.k, self.n = k.value, 1 << k.value
+
+    @classmethod
+    def read_ptau(cls, ctx, data: bytes):
+        h = C.c_void_p()
+        _check(lib().shp_srs_from_ptau(ctx.h, C.c_char_p(data), C.c_size_t(len(data)), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def read_raw(cls, ctx, data: bytes):
+        h = C.c_void_p()
+        _check(lib().shp_srs_from_halo2_raw(ctx.h, C.c_char_p(data), C.c_size_t(len(data)), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_parts(cls, ctx, k, g, g_lagrange=None, g2=None, s_g2=None):
+        g = np.ascontiguousarray(g, dtype=np.uint64)
+        gl = None if g_lagrange is None else np.ascontiguousarray(g_lagrange, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().shp_srs_from_parts(ctx.h, C.c_uint32(k), g.ctypes.data_as(C.c_void_p),
+                                        gl.ctypes.data_as(C.c_void_p) if gl is not None else None,
+                                        C.c_char_p(g2) if g2 else None, C.c_char_p(s_g2) if s_g2 else None,
+                                        C.byref(h)))
+        return cls(ctx, h)
+
+    def get_g(self, basis=BASIS_MONOMIAL):
+        out = np.zeros((self.n, 8), dtype=np.uint64)
+        _check(lib().shp_srs_get_g(self.h, C.c_int32(basis), out.ctypes.data_as(C.c_void_p), C.c_size_t(self.n)))
+        return out
+
+    def g2(self):
+        a, b = C.create_string_buffer(128), C.create_string_buffer(128)
+        _check(lib().shp_srs_get_g2(self.h, a, b))
+        return a.raw, b.raw
+
+    def commit(self, t_polys, batch=1, basis=BASIS_MONOMIAL):
+        out = np.zeros((batch, 8), dtype=np.uint64)
+        _check(lib().shp_srs_commit(self.h, C.c_int32(basis), _vp(t_polys.data_ptr()), C.c_uint32(batch),
+                                    out.ctypes.data_as(C.c_void_p), _stream()))
+        return out
+
+    def commit_lagrange(self, t_polys, batch=1):
+        return self.commit(t_polys, batch, BASIS_LAGRANGE)
+
+    def close(self):
+        if self.h:
+            lib().shp_srs_destroy(self.h)
+            self.h = C.c_void_p()

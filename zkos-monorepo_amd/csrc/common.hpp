@@ -1,0 +1,76 @@
+// Shared host-side plumbing of libshielder_hip: status codes, last-error slot, HIP call
+// checking, a grow-only device workspace.  No torch types, no oracle code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <stdexcept>
+#include <vector>
+
+#include "../../include/shielder_hip.h"
+
+namespace shp {
+
+void set_last_error(const std::string& msg);
+
+struct Error : std::runtime_error {
+    int32_t code;
+    Error(int32_t c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define SHP_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            throw ::shp::Error(SHP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define SHP_REQUIRE(cond, code, msg)                          \
+    do {                                                      \
+        if (!(cond)) throw ::shp::Error((code), (msg));       \
+    } while (0)
+
+// every extern "C" entry point runs its body through this: nothing unwinds across the ABI
+template <class F>
+static inline int32_t guarded(F&& f) {
+    try {
+        f();
+        return SHP_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return SHP_ERR_INTERNAL;
+    } catch (...) {
+        set_last_error("unknown exception");
+        return SHP_ERR_INTERNAL;
+    }
+}
+
+// grow-only device buffer (workspace that survives across calls; never freed in a launch path)
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) SHP_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + (bytes >> 2);
+        SHP_HIP(hipMalloc(&p, want));
+        cap = want;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+static inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace shp

@@ -1,0 +1,54 @@
+// The per-(process, GPU) context behind shp_ctx.
+#pragma once
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include "common.hpp"
+#include "field.cuh"
+
+namespace shp {
+
+// Twiddle tables of one NTT size (device resident, built once):
+//   small[j]   = w_2048^j            j < 1024   (butterflies inside an LDS tile; shared by all sizes)
+//   lo[j]      = w_N^j               j < 2^h    } inter-pass twiddle w_N^e = hi[e >> h] * lo[e & (2^h-1)]
+//   hi[j]      = w_N^(j * 2^h)       j < 2^(log_n - h)
+struct NttTables {
+    uint32_t log_n = 0, h = 0;
+    Fr* lo[2] = {nullptr, nullptr};      // [0] forward, [1] inverse
+    Fr* hi[2] = {nullptr, nullptr};
+    Fr n_inv;
+};
+
+}  // namespace shp
+
+struct shp_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    std::mutex mu;
+    shp::Fr* ntt_small[2] = {nullptr, nullptr};          // w_2048^j and its inverse powers
+    std::map<uint32_t, shp::NttTables> ntt_tables;
+    shp::DevBuf ntt_tmp;                                  // ping-pong buffer of the multi-pass NTT
+    shp::Fr zeta, zeta2;                                  // coset generator of the extended domain
+
+    hipStream_t pick(void* s) const { return s ? reinterpret_cast<hipStream_t>(s) : stream; }
+};
+
+namespace shp {
+const NttTables& ntt_tables_for(shp_ctx* ctx, uint32_t log_n);
+Fr fr_root_of_unity(uint32_t k);     // primitive 2^k-th root (host)
+Fr fr_zeta();                         // 7^((r-1)/3)
+Fr fr_delta();                        // 7^(2^28)
+
+// launchers used by the C ABI and the prover
+struct NttOpts {
+    bool inverse = false;     // w^-1 tables and 1/n scaling
+    uint32_t in_len = 0;      // 0 = 2^log_n; else elements >= in_len of each input poly read as zero
+    size_t in_stride = 0;     // elements between input polys (0 = in_len or 2^log_n)
+    int pre_pattern = 0;      // 1: input i scaled by [1, zeta, zeta^2][i % 3]
+    int post_pattern = 0;     // 1: output i scaled by [1, zeta^2, zeta][i % 3]
+};
+void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_t batch, const NttOpts& o,
+                hipStream_t st);
+}  // namespace shp

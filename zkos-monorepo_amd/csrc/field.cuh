@@ -1,0 +1,281 @@
+// BN254 prime-field arithmetic for the HIP path (device) and the host driver.
+//
+// Representation: 8 x u32 little-endian limbs, Montgomery form with R = 2^256 -- byte
+// for byte the 4 x u64 Montgomery limbs of the reference's SRS files
+// (/root/reference/crates/powers-of-tau/lib.rs:92-109, 206-227), so SRS tables, proving
+// keys and witnesses are used in HBM exactly as they arrive.
+//
+// The multiplier is a CIOS Montgomery product on 32-bit limbs: every partial product is
+// one v_mad_u64_u32 (32x32+64 -> 64) on CDNA4; there is no MFMA formulation of a 254-bit
+// modular product worth its operand shuffling (BASELINE.json north_star).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SHP_HD __host__ __device__ __forceinline__
+#else
+#define SHP_HD inline
+#endif
+
+namespace shp {
+
+struct FqParams {
+    static SHP_HD constexpr uint32_t p(int i) {
+        constexpr uint32_t v[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return v[i];
+    }
+    static SHP_HD constexpr uint32_t r1(int i) {   // R mod p  (Montgomery one)
+        constexpr uint32_t v[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return v[i];
+    }
+    static SHP_HD constexpr uint32_t r2(int i) {   // R^2 mod p
+        constexpr uint32_t v[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+        return v[i];
+    }
+    static SHP_HD constexpr uint32_t r3(int i) {   // R^3 mod p
+        constexpr uint32_t v[8] = {0xda1530dfu, 0xb1cd6dafu, 0xa7283db6u, 0x62f210e6u, 0x0ada0afbu, 0xef7f0b0cu, 0x2d592544u, 0x20fd6e90u};
+        return v[i];
+    }
+    static constexpr uint32_t INV = 0xe4866389u;   // -p^{-1} mod 2^32
+};
+
+struct FrParams {
+    static SHP_HD constexpr uint32_t p(int i) {
+        constexpr uint32_t v[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return v[i];
+    }
+    static SHP_HD constexpr uint32_t r1(int i) {
+        constexpr uint32_t v[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return v[i];
+    }
+    static SHP_HD constexpr uint32_t r2(int i) {
+        constexpr uint32_t v[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+        return v[i];
+    }
+    static SHP_HD constexpr uint32_t r3(int i) {
+        constexpr uint32_t v[8] = {0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu, 0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu};
+        return v[i];
+    }
+    static constexpr uint32_t INV = 0xefffffffu;
+};
+
+template <class PR>
+struct alignas(16) Fp {
+    uint32_t l[8];
+
+    static SHP_HD Fp zero() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = 0;
+        return r;
+    }
+    static SHP_HD Fp one() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = PR::r1(i);
+        return r;
+    }
+    static SHP_HD Fp modulus() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = PR::p(i);
+        return r;
+    }
+    SHP_HD bool is_zero() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= l[i];
+        return o == 0;
+    }
+    SHP_HD bool operator==(const Fp& b) const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= l[i] ^ b.l[i];
+        return o == 0;
+    }
+    SHP_HD bool operator!=(const Fp& b) const { return !(*this == b); }
+
+    // raw limb vector >= modulus ?
+    SHP_HD bool geq_p() const {
+#pragma unroll
+        for (int i = 7; i >= 0; i--) {
+            if (l[i] > PR::p(i)) return true;
+            if (l[i] < PR::p(i)) return false;
+        }
+        return true;
+    }
+    // raw a < b (as 256-bit integers)
+    static SHP_HD bool raw_lt(const Fp& a, const Fp& b) {
+#pragma unroll
+        for (int i = 7; i >= 0; i--) {
+            if (a.l[i] < b.l[i]) return true;
+            if (a.l[i] > b.l[i]) return false;
+        }
+        return false;
+    }
+
+    // r = a - p if a >= p (branch-free select)
+    SHP_HD void reduce_once() {
+        uint32_t t[8];
+        uint64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t d = (uint64_t)l[i] - PR::p(i) - bw;
+            t[i] = (uint32_t)d;
+            bw = (d >> 32) & 1;
+        }
+        if (!bw) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) l[i] = t[i];
+        }
+    }
+
+    static SHP_HD Fp add(const Fp& a, const Fp& b) {
+        Fp r;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            c += (uint64_t)a.l[i] + b.l[i];
+            r.l[i] = (uint32_t)c;
+            c >>= 32;
+        }
+        r.reduce_once();     // p < 2^254: no carry out of limb 7
+        return r;
+    }
+    static SHP_HD Fp sub(const Fp& a, const Fp& b) {
+        Fp r;
+        uint64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t d = (uint64_t)a.l[i] - b.l[i] - bw;
+            r.l[i] = (uint32_t)d;
+            bw = (d >> 32) & 1;
+        }
+        uint32_t mask = (uint32_t)0 - (uint32_t)bw;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            c += (uint64_t)r.l[i] + (PR::p(i) & mask);
+            r.l[i] = (uint32_t)c;
+            c >>= 32;
+        }
+        return r;
+    }
+    static SHP_HD Fp neg(const Fp& a) {
+        if (a.is_zero()) return a;
+        Fp r;
+        uint64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t d = (uint64_t)PR::p(i) - a.l[i] - bw;
+            r.l[i] = (uint32_t)d;
+            bw = (d >> 32) & 1;
+        }
+        return r;
+    }
+    static SHP_HD Fp dbl(const Fp& a) { return add(a, a); }
+
+    // Montgomery product a*b/R mod p. Operands may be any 256-bit values with a*b < p*R
+    // (so raw, unreduced inputs such as ChaCha output are allowed against a reduced one).
+    static SHP_HD Fp mul(const Fp& a, const Fp& b) {
+        uint32_t t[8];
+        uint32_t t8 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) t[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t c = 0;
+            const uint32_t bi = b.l[i];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                c += (uint64_t)a.l[j] * bi + t[j];
+                t[j] = (uint32_t)c;
+                c >>= 32;
+            }
+            uint64_t top = (uint64_t)t8 + c;             // < 2^33
+            const uint32_t m = t[0] * PR::INV;
+            c = ((uint64_t)m * PR::p(0) + t[0]) >> 32;
+#pragma unroll
+            for (int j = 1; j < 8; j++) {
+                c += (uint64_t)m * PR::p(j) + t[j];
+                t[j - 1] = (uint32_t)c;
+                c >>= 32;
+            }
+            top += c;
+            t[7] = (uint32_t)top;
+            t8 = (uint32_t)(top >> 32);
+        }
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = t[i];
+        // t8 is 0 for p < 2^254 with reduced inputs; with one raw 256-bit input the value is
+        // still < 2p, and 2p < 2^256, so a single conditional subtraction is enough.
+        r.reduce_once();
+        return r;
+    }
+    static SHP_HD Fp sqr(const Fp& a) { return mul(a, a); }
+
+    SHP_HD Fp operator+(const Fp& b) const { return add(*this, b); }
+    SHP_HD Fp operator-(const Fp& b) const { return sub(*this, b); }
+    SHP_HD Fp operator*(const Fp& b) const { return mul(*this, b); }
+
+    // canonical integer (raw limbs) -> Montgomery
+    static SHP_HD Fp from_raw(const Fp& raw) {
+        Fp r2;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r2.l[i] = PR::r2(i);
+        return mul(raw, r2);
+    }
+    // Montgomery -> canonical integer
+    SHP_HD Fp to_raw() const {
+        Fp o = zero();
+        o.l[0] = 1;
+        return mul(*this, o);
+    }
+    static SHP_HD Fp from_u64(uint64_t v) {
+        Fp r = zero();
+        r.l[0] = (uint32_t)v;
+        r.l[1] = (uint32_t)(v >> 32);
+        return from_raw(r);
+    }
+    // 64 uniform bytes (two raw 256-bit halves) -> d0*R^2 + d1*R^3 (halo2curves from_u512)
+    static SHP_HD Fp from_u512(const Fp& d0, const Fp& d1) {
+        Fp r2, r3;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { r2.l[i] = PR::r2(i); r3.l[i] = PR::r3(i); }
+        return add(mul(d0, r2), mul(d1, r3));
+    }
+
+    // a^e, e a raw 256-bit exponent (MSB-first square and multiply)
+    static SHP_HD Fp pow(const Fp& a, const Fp& e) {
+        Fp acc = one();
+        bool started = false;
+        for (int i = 255; i >= 0; i--) {
+            if (started) acc = sqr(acc);
+            if ((e.l[i >> 5] >> (i & 31)) & 1) {
+                acc = started ? mul(acc, a) : a;
+                started = true;
+            }
+        }
+        return acc;
+    }
+    static SHP_HD Fp pow_u64(const Fp& a, uint64_t e) {
+        Fp ee = zero();
+        ee.l[0] = (uint32_t)e;
+        ee.l[1] = (uint32_t)(e >> 32);
+        return pow(a, ee);
+    }
+    // a^(p-2); 0 -> 0
+    static SHP_HD Fp inv(const Fp& a) {
+        if (a.is_zero()) return a;
+        Fp e = modulus();
+        e.l[0] -= 2;      // p is odd and p[0] >= 2
+        return pow(a, e);
+    }
+};
+
+using Fq = Fp<FqParams>;
+using Fr = Fp<FrParams>;
+
+}  // namespace shp

@@ -1,0 +1,314 @@
+// Radix-2 NTT / iNTT over BN254 Fr for gfx950.
+//
+// Replaces halo2_proofs v0.3.0 EvaluationDomain::{best_fft, lagrange_to_coeff,
+// coeff_to_extended, extended_to_coeff} on the proving path (SURVEY.md section 8a rows a10/a4;
+// conventions pinned by /root/reference/resources/ppot_0080_11_raw's g_lagrange and the delta
+// literal at /root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:475).
+//
+// Design (HBM-bound shape, integer-ALU-bound in practice):
+//   * N = L1 * L2 [* L3].  One pass per digit; a pass moves every element HBM -> LDS -> HBM
+//     exactly once, so a transform costs P x 64 B/element of traffic with P in {1,2,3}.
+//   * A workgroup owns a 2048-element LDS tile (64 KiB, two 16-byte planes so that
+//     ds_read_b128/ds_write_b128 are lane-contiguous and bank-conflict free) holding 2^c
+//     independent length-2^s sub-transforms whose elements are ADJACENT in memory: every
+//     global access is a run of 2^c * 32 B >= 128 B.
+//   * Inside the tile: s decimation-in-frequency stages, twiddles from a 32 KiB table of
+//     w_2048^j that stays in L2; the bit reversal is folded into the read-out index.
+//   * Between passes: the element is scaled by w_N^(k_p * lo) = hi[e >> h] * lo[e & mask]
+//     (two small L2-resident tables instead of an N-entry table that would double the traffic).
+//   * The last pass writes in digit-reversed = natural order, 2^c adjacent outputs per run,
+//     so there is no separate bit-reversal sweep.  1/n, and the zeta-coset scalings of
+//     coeff_to_extended / extended_to_coeff, are fused into the first load / last store.
+#include "ctx.hpp"
+
+namespace shp {
+
+constexpr int NTT_TILE_LOG = 11;
+constexpr int NTT_THREADS = 256;
+
+struct PassParams {
+    const Fr* src;
+    Fr* dst;
+    size_t src_stride, dst_stride;
+    uint32_t log_n, s, lo_bits, c, s1, s2, h;
+    uint32_t in_len;
+    int is_first, is_final, pre_pattern, post_pattern, do_scale;
+    const Fr* small_tw;
+    const Fr* tw_lo;
+    const Fr* tw_hi;
+    Fr scale, zeta, zeta2;
+};
+
+__device__ __forceinline__ Fr lds_load(const uint4* lo, const uint4* hi, uint32_t i) {
+    Fr r;
+    uint4 a = lo[i], b = hi[i];
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void lds_store(uint4* lo, uint4* hi, uint32_t i, const Fr& v) {
+    lo[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    hi[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+__device__ __forceinline__ Fr gload(const Fr* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void gstore(Fr* p, const Fr& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassParams p) {
+    __shared__ uint4 sh_lo[1 << NTT_TILE_LOG];
+    __shared__ uint4 sh_hi[1 << NTT_TILE_LOG];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const Fr* src = p.src + (size_t)blockIdx.y * p.src_stride;
+    Fr* dst = p.dst + (size_t)blockIdx.y * p.dst_stride;
+    const uint32_t s = p.s, c = p.c;
+    const uint32_t L = 1u << s, V = 1u << c, E = L << c;
+
+    // ---- tile coordinates
+    uint32_t hi = 0, lo_base = 0, k1_base = 0, k2 = 0;
+    if (!p.is_final) {
+        uint32_t lo_tiles_log = p.lo_bits - c;
+        hi = tile >> lo_tiles_log;
+        lo_base = (tile & ((1u << lo_tiles_log) - 1)) << c;
+    } else {
+        k2 = tile & ((1u << p.s2) - 1);
+        k1_base = (tile >> p.s2) << c;
+    }
+
+    // ---- load HBM -> LDS
+    for (uint32_t e = tid; e < E; e += NTT_THREADS) {
+        size_t gi;
+        uint32_t li;
+        if (!p.is_final) {
+            uint32_t v = e & (V - 1), j = e >> c;
+            gi = ((size_t)hi << (s + p.lo_bits)) | ((size_t)j << p.lo_bits) | (lo_base | v);
+            li = e;    // j * V + v
+        } else {
+            uint32_t j = e & (L - 1), r = e >> s;
+            uint32_t k1 = k1_base | r;
+            gi = ((((size_t)k1 << p.s2) | k2) << s) | j;
+            li = j * V + r;
+        }
+        Fr val;
+        if (p.is_first && gi >= p.in_len) {
+            val = Fr::zero();
+        } else {
+            val = gload(src + gi);
+            if (p.is_first && p.pre_pattern) {
+                uint32_t m = (uint32_t)(gi % 3);
+                if (m == 1) val = val * p.zeta;
+                else if (m == 2) val = val * p.zeta2;
+            }
+        }
+        lds_store(sh_lo, sh_hi, li, val);
+    }
+    __syncthreads();
+
+    // ---- s decimation-in-frequency stages in LDS
+    for (int t = (int)s - 1; t >= 0; t--) {
+        const uint32_t half = 1u << t;
+        for (uint32_t b = tid; b < (E >> 1); b += NTT_THREADS) {
+            uint32_t v = b & (V - 1), jb = b >> c;
+            uint32_t grp = jb >> t, pos = jb & (half - 1);
+            uint32_t j0 = (grp << (t + 1)) | pos;
+            uint32_t i0 = j0 * V + v, i1 = (j0 + half) * V + v;
+            Fr a = lds_load(sh_lo, sh_hi, i0);
+            Fr bb = lds_load(sh_lo, sh_hi, i1);
+            Fr u = a + bb;
+            Fr d = a - bb;
+            if (pos) d = d * gload(p.small_tw + ((size_t)pos << (10 - t)));
+            lds_store(sh_lo, sh_hi, i0, u);
+            lds_store(sh_lo, sh_hi, i1, d);
+        }
+        __syncthreads();
+    }
+
+    // ---- store LDS -> HBM (bit reversal folded into the LDS read index)
+    const uint32_t hi_bits = p.log_n - s - p.lo_bits;
+    for (uint32_t e = tid; e < E; e += NTT_THREADS) {
+        uint32_t v = e & (V - 1), kp = e >> c;
+        uint32_t j = s ? (__brev(kp) >> (32 - s)) : 0;
+        Fr val = lds_load(sh_lo, sh_hi, j * V + v);
+        size_t go;
+        if (!p.is_final) {
+            uint32_t lo = lo_base | v;
+            go = ((size_t)hi << (s + p.lo_bits)) | ((size_t)kp << p.lo_bits) | lo;
+            uint64_t et = ((uint64_t)kp * lo) << hi_bits;
+            if (et) {
+                Fr tw = gload(p.tw_hi + (et >> p.h)) * gload(p.tw_lo + (et & ((1u << p.h) - 1)));
+                val = val * tw;
+            }
+        } else {
+            uint32_t k1 = k1_base | v;
+            go = (size_t)k1 + ((size_t)k2 << p.s1) + ((size_t)kp << (p.s1 + p.s2));
+            if (p.do_scale) val = val * p.scale;
+            if (p.post_pattern) {
+                uint32_t m = (uint32_t)(go % 3);
+                if (m == 1) val = val * p.zeta2;
+                else if (m == 2) val = val * p.zeta;
+            }
+        }
+        gstore(dst + go, val);
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static Fr pow2k(Fr x, uint32_t times) {
+    for (uint32_t i = 0; i < times; i++) x = Fr::sqr(x);
+    return x;
+}
+
+static Fr fr_root28() {
+    // 7^((r-1) >> 28)
+    Fr e = Fr::modulus();
+    e.l[0] -= 1;
+    Fr sh = Fr::zero();
+    for (int i = 0; i < 8; i++) {
+        uint64_t v = e.l[i] >> 28;
+        if (i < 7) v |= (uint64_t)e.l[i + 1] << 4;
+        sh.l[i] = (uint32_t)v;
+    }
+    return Fr::pow(Fr::from_u64(7), sh);
+}
+
+Fr fr_root_of_unity(uint32_t k) {
+    static const Fr root = fr_root28();
+    SHP_REQUIRE(k <= 28, SHP_ERR_INVALID_ARG, "log_n > 28");
+    return pow2k(root, 28 - k);
+}
+Fr fr_delta() { return Fr::pow_u64(Fr::from_u64(7), 1ull << 28); }
+Fr fr_zeta() {
+    // (r-1)/3 by long division over the 32-bit limbs
+    Fr e = Fr::modulus();
+    e.l[0] -= 1;
+    Fr q = Fr::zero();
+    uint64_t rem = 0;
+    for (int i = 7; i >= 0; i--) {
+        uint64_t cur = (rem << 32) | e.l[i];
+        q.l[i] = (uint32_t)(cur / 3);
+        rem = cur % 3;
+    }
+    return Fr::pow(Fr::from_u64(7), q);
+}
+
+static Fr* upload_powers(const Fr& base, size_t count) {
+    std::vector<Fr> v(count);
+    Fr acc = Fr::one();
+    for (size_t i = 0; i < count; i++) {
+        v[i] = acc;
+        acc = acc * base;
+    }
+    Fr* d = nullptr;
+    SHP_HIP(hipMalloc(&d, count * sizeof(Fr)));
+    SHP_HIP(hipMemcpy(d, v.data(), count * sizeof(Fr), hipMemcpyHostToDevice));
+    return d;
+}
+
+const NttTables& ntt_tables_for(shp_ctx* ctx, uint32_t log_n) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!ctx->ntt_small[0]) {
+        Fr w = fr_root_of_unity(11);
+        ctx->ntt_small[0] = upload_powers(w, 1024);
+        ctx->ntt_small[1] = upload_powers(Fr::inv(w), 1024);
+        ctx->zeta = fr_zeta();
+        ctx->zeta2 = Fr::sqr(ctx->zeta);
+    }
+    auto it = ctx->ntt_tables.find(log_n);
+    if (it != ctx->ntt_tables.end()) return it->second;
+    NttTables t;
+    t.log_n = log_n;
+    t.h = (log_n + 1) / 2;
+    Fr w = fr_root_of_unity(log_n);
+    Fr wi = Fr::inv(w);
+    t.lo[0] = upload_powers(w, (size_t)1 << t.h);
+    t.lo[1] = upload_powers(wi, (size_t)1 << t.h);
+    t.hi[0] = upload_powers(pow2k(w, t.h), (size_t)1 << (log_n - t.h));
+    t.hi[1] = upload_powers(pow2k(wi, t.h), (size_t)1 << (log_n - t.h));
+    t.n_inv = Fr::inv(Fr::from_u64(1ull << log_n));
+    return ctx->ntt_tables.emplace(log_n, t).first->second;
+}
+
+void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_t batch, const NttOpts& o,
+                hipStream_t st) {
+    SHP_REQUIRE(log_n >= 1 && log_n <= 27, SHP_ERR_INVALID_ARG, "ntt: log_n out of range [1,27]");
+    if (batch == 0) return;
+    const NttTables& T = ntt_tables_for(ctx, log_n);
+    const size_t N = (size_t)1 << log_n;
+    const int dir = o.inverse ? 1 : 0;
+
+    uint32_t digits[3] = {0, 0, 0};
+    int P;
+    if (log_n <= NTT_TILE_LOG) {
+        P = 1;
+        digits[0] = log_n;
+    } else if (log_n <= 18) {
+        P = 2;
+        digits[1] = log_n / 2;
+        digits[0] = log_n - digits[1];
+    } else {
+        P = 3;
+        digits[2] = log_n / 3;
+        digits[1] = (log_n - digits[2]) / 2;
+        digits[0] = log_n - digits[1] - digits[2];
+    }
+    Fr* tmp = nullptr;
+    if (P > 1) {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        ctx->ntt_tmp.reserve((size_t)batch * N * sizeof(Fr));
+        tmp = ctx->ntt_tmp.as<Fr>();
+    }
+    const uint32_t in_len = o.in_len ? o.in_len : (uint32_t)N;
+    const size_t in_stride = o.in_stride ? o.in_stride : (o.in_len ? o.in_len : N);
+
+    uint32_t consumed = 0;
+    for (int pass = 0; pass < P; pass++) {
+        PassParams p;
+        p.log_n = log_n;
+        p.s = digits[pass];
+        p.is_first = pass == 0;
+        p.is_final = pass == P - 1;
+        p.lo_bits = log_n - consumed - p.s;
+        p.s1 = 0;
+        p.s2 = 0;
+        if (p.is_final) {
+            if (P == 2) p.s1 = digits[0];
+            if (P == 3) { p.s1 = digits[0]; p.s2 = digits[1]; }
+            uint32_t cmax = NTT_TILE_LOG - p.s;
+            p.c = cmax < p.s1 ? cmax : p.s1;
+        } else {
+            uint32_t cmax = NTT_TILE_LOG - p.s;
+            p.c = cmax < p.lo_bits ? cmax : p.lo_bits;
+        }
+        p.h = T.h;
+        p.in_len = in_len;
+        p.pre_pattern = o.pre_pattern;
+        p.post_pattern = o.post_pattern;
+        p.do_scale = o.inverse ? 1 : 0;
+        p.scale = T.n_inv;
+        p.zeta = ctx->zeta;
+        p.zeta2 = ctx->zeta2;
+        p.small_tw = ctx->ntt_small[dir];
+        p.tw_lo = T.lo[dir];
+        p.tw_hi = T.hi[dir];
+        if (p.is_first) { p.src = d_in; p.src_stride = in_stride; }
+        else { p.src = tmp; p.src_stride = N; }
+        if (p.is_final) { p.dst = d_out; p.dst_stride = N; }
+        else { p.dst = tmp; p.dst_stride = N; }
+        uint32_t tiles = (uint32_t)(N >> (p.s + p.c));
+        hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, batch), dim3(NTT_THREADS), 0, st, p);
+        SHP_HIP(hipGetLastError());
+        consumed += p.s;
+    }
+}
+
+}  // namespace shp
