@@ -60,6 +60,8 @@ int32_t shp_device_count(int32_t* out);
 int32_t shp_ctx_create(int32_t device, shp_ctx** out);
 int32_t shp_ctx_destroy(shp_ctx* ctx);
 int32_t shp_ctx_sync(shp_ctx* ctx);                       /* wait for the context's stream */
+/* the context's hipStream_t (so that a caller can order its own copies/kernels on it) */
+int32_t shp_ctx_stream(shp_ctx* ctx, void** stream_out);
 
 /* plain device-memory helpers so that callers without a HIP runtime binding (cgo, ctypes) can
  * keep inputs resident in HBM */

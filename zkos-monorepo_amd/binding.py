@@ -99,6 +99,14 @@ class Context:
         self.h = C.c_void_p()
         _check(lib().shp_ctx_create(C.c_int32(device), C.byref(self.h)))
         self.device = device
+        # torch is plumbing only: make the context's HIP stream torch's current stream, so that
+        # torch copies, torch.cuda.Event timing and the library's kernels are ordered on ONE stream
+        import torch
+        sp = C.c_void_p()
+        _check(lib().shp_ctx_stream(self.h, C.byref(sp)))
+        torch.cuda.set_device(device)
+        self.torch_stream = torch.cuda.ExternalStream(sp.value, device=device)
+        torch.cuda.set_stream(self.torch_stream)
 
     def close(self):
         if self.h:

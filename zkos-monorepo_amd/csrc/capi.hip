@@ -203,6 +203,13 @@ int32_t shp_ctx_sync(shp_ctx* ctx) {
     });
 }
 
+int32_t shp_ctx_stream(shp_ctx* ctx, void** stream_out) {
+    return guarded([&] {
+        SHP_REQUIRE(ctx && stream_out, SHP_ERR_INVALID_ARG, "ctx_stream: null argument");
+        *stream_out = (void*)ctx->stream;
+    });
+}
+
 int32_t shp_malloc(shp_ctx* ctx, size_t bytes, void** d_out) {
     return guarded([&] {
         SHP_REQUIRE(ctx && d_out, SHP_ERR_INVALID_ARG, "malloc: null argument");
