@@ -51,6 +51,8 @@ enum {
 typedef struct shp_ctx shp_ctx;   /* one per (process, GPU): streams, workspaces, twiddle tables */
 typedef struct shp_srs shp_srs;   /* device-resident KZG SRS ("Params") */
 typedef struct shp_msm shp_msm;   /* fixed-base MSM plan over one table of bases */
+typedef struct shp_pk shp_pk;     /* device-resident proving key ("ProvingKey" + its VerifyingKey) */
+typedef struct shp_prover shp_prover; /* one proving lane: a HIP stream + its workspace in HBM */
 
 /* ---- library / device ------------------------------------------------------------ */
 const char* shp_last_error(void);
@@ -126,6 +128,37 @@ int32_t shp_srs_get_g2(const shp_srs* srs, uint8_t g2_128[128], uint8_t s_g2_128
 /* Params::commit / commit_lagrange on `batch` device-resident polynomials of 2^k Fr each */
 int32_t shp_srs_commit(shp_srs* srs, int32_t basis, const void* d_polys, uint32_t batch, void* h_out_affine,
                        void* stream);
+
+/* ---- proving key and prover ---------------------------------------------------------- */
+/* generate_keys_with_min_k + unmarshall_pk (/root/reference/crates/shielder_bindings/build.rs:19-32,
+ * src/circuits/mod.rs:38-46): builds the device-resident proving key of the circuit described by
+ * `plan` (circuit plan v1: DESIGN.md, zkos-monorepo_amd/circuits/builder.py) over `srs`, which must
+ * outlive the key.  Fixed/permutation polynomials, their extended cosets and commitments are
+ * computed on the GPU. */
+int32_t shp_keygen(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan, size_t plan_len, shp_pk** out);
+int32_t shp_pk_destroy(shp_pk* pk);
+int32_t shp_pk_info(const shp_pk* pk, uint32_t* k, uint32_t* n_witness_inputs, uint32_t* n_instances,
+                    uint32_t* proof_len);
+/* verifying-key material: transcript digest, fixed and permutation commitments (64 B affine each) */
+int32_t shp_pk_vk_digest(const shp_pk* pk, uint8_t out[32]);
+int32_t shp_pk_commitments(const shp_pk* pk, void* h_fixed, size_t n_fixed, void* h_sigma, size_t n_sigma);
+/* A proving lane.  Lanes of one key may prove concurrently from different host threads. */
+int32_t shp_prover_create(shp_pk* pk, shp_prover** out);
+int32_t shp_prover_destroy(shp_prover* p);
+/* generate_proof(&params, &pk, circuit, &pub_input, rng) -> Vec<u8>
+ * (/root/reference/crates/shielder_bindings/src/circuits/mod.rs:103-111).
+ *   witness_le32   n_inputs x 32-byte little-endian CANONICAL field elements in the circuit's
+ *                  witness-input order (for the withdraw plan: the argument order of
+ *                  WithdrawCircuit::prove, src/circuits/withdraw.rs:88-114); SHP_ERR_FORMAT if >= r
+ *   seed           32 bytes keying the ChaCha20 blinding stream (the reference's `rng`); Fr draw i is
+ *                  from_u512(ChaCha20(seed, block i)), consumed in the order documented in DESIGN.md
+ *   proof_out      caller buffer (capacity proof_cap, >= shp_pk_info proof_len); *proof_len is set
+ *   instances_le32 optional: the public inputs (serialize_public_input), 32-byte LE canonical each */
+int32_t shp_prove(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, const uint8_t seed[32],
+                  uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* instances_le32,
+                  size_t instances_cap);
+/* poseidon::off_circuit::hash on the host (shielder_bindings/src/hash.rs:17-26): 32-byte LE canonical */
+int32_t shp_poseidon2_hash_host(const uint8_t* inputs_le32, uint32_t arity, uint8_t out_le32[32]);
 
 /* ---- diagnostics ------------------------------------------------------------------- */
 /* sustained Fr Montgomery products per second with every CU busy: the integer-ALU ceiling that

@@ -244,3 +244,68 @@ class Params:
         if self.h:
             lib().shp_srs_destroy(self.h)
             self.h = C.c_void_p()
+
+
+def poseidon2_hash_host(ints):
+    """poseidon::off_circuit::hash on canonical python ints (host path of the library)"""
+    buf = b"".join(int(x).to_bytes(32, "little") for x in ints)
+    out = C.create_string_buffer(32)
+    _check(lib().shp_poseidon2_hash_host(C.c_char_p(buf), C.c_uint32(len(ints)), out))
+    return int.from_bytes(out.raw, "little")
+
+
+class ProvingKey:
+    """Device-resident proving key of one circuit plan (the reference's `ProvingKey` + vk)."""
+
+    def __init__(self, ctx: Context, params: Params, plan: bytes):
+        self.ctx, self.params = ctx, params
+        self.h = C.c_void_p()
+        _check(lib().shp_keygen(ctx.h, params.h, C.c_char_p(plan), C.c_size_t(len(plan)), C.byref(self.h)))
+        k, ni, nins, pl = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib().shp_pk_info(self.h, C.byref(k), C.byref(ni), C.byref(nins), C.byref(pl)))
+        self.k, self.n_inputs, self.n_instances, self.proof_len = k.value, ni.value, nins.value, pl.value
+
+    def vk_digest(self) -> bytes:
+        out = C.create_string_buffer(32)
+        _check(lib().shp_pk_vk_digest(self.h, out))
+        return out.raw
+
+    def commitments(self, n_fixed, n_sigma):
+        f = np.zeros((n_fixed, 8), dtype=np.uint64)
+        s = np.zeros((n_sigma, 8), dtype=np.uint64)
+        _check(lib().shp_pk_commitments(self.h, f.ctypes.data_as(C.c_void_p), C.c_size_t(n_fixed),
+                                        s.ctypes.data_as(C.c_void_p), C.c_size_t(n_sigma)))
+        return f, s
+
+    def close(self):
+        if self.h:
+            lib().shp_pk_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Prover:
+    """One proving lane (HIP stream + HBM workspace): generate_proof(params, pk, circuit, pub_input, rng)."""
+
+    def __init__(self, pk: ProvingKey):
+        self.pk = pk
+        self.h = C.c_void_p()
+        _check(lib().shp_prover_create(pk.h, C.byref(self.h)))
+
+    def prove(self, witness_ints, seed: bytes):
+        """witness_ints: canonical python ints in the plan's witness-input order -> (proof, instances)"""
+        assert len(seed) == 32
+        return self.prove_bytes(b"".join(int(x).to_bytes(32, "little") for x in witness_ints), seed)
+
+    def prove_bytes(self, wit: bytes, seed: bytes):
+        proof = C.create_string_buffer(self.pk.proof_len)
+        plen = C.c_size_t()
+        inst = C.create_string_buffer(32 * self.pk.n_instances)
+        _check(lib().shp_prove(self.h, C.c_char_p(wit), C.c_size_t(len(wit) // 32), C.c_char_p(seed), proof,
+                               C.c_size_t(self.pk.proof_len), C.byref(plen), inst, C.c_size_t(len(inst.raw))))
+        ins = [int.from_bytes(inst.raw[32 * i:32 * i + 32], "little") for i in range(self.pk.n_instances)]
+        return proof.raw[:plen.value], ins
+
+    def close(self):
+        if self.h:
+            lib().shp_prover_destroy(self.h)
+            self.h = C.c_void_p()

@@ -2,8 +2,7 @@
 // management, the field front door, the NTT entry points and the SRS ("Params") object.
 #include <string.h>
 
-#include "ctx.hpp"
-#include "curve.cuh"
+#include "engine.hpp"
 
 namespace shp {
 
@@ -93,21 +92,6 @@ static bool on_curve(const G1Affine& p) {
 }  // namespace shp
 
 using namespace shp;
-
-void msm_run(shp_msm* m, const Fr* d_scalars, size_t n_scalars, size_t stride, uint32_t batch, G1Affine* h_out,
-             hipStream_t st);
-
-struct shp_srs {
-    shp_ctx* ctx = nullptr;
-    uint32_t k = 0;
-    size_t n = 0;
-    G1Affine* d_g = nullptr;
-    G1Affine* d_gl = nullptr;
-    shp_msm* msm_g = nullptr;
-    shp_msm* msm_gl = nullptr;
-    uint8_t g2[128] = {0}, s_g2[128] = {0};
-    bool has_g2 = false;
-};
 
 static void srs_finish(shp_srs* s) {
     int32_t rc = shp_msm_create_dev(s->ctx, s->d_g, s->n, 0, &s->msm_g);

@@ -49,6 +49,8 @@ struct NttOpts {
     int pre_pattern = 0;      // 1: input i scaled by [1, zeta, zeta^2][i % 3]
     int post_pattern = 0;     // 1: output i scaled by [1, zeta^2, zeta][i % 3]
 };
+// `tmp`: caller-owned ping-pong buffer of batch * 2^log_n elements (needed when log_n > 11);
+// nullptr = the context's shared buffer (single-stream use only)
 void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_t batch, const NttOpts& o,
-                hipStream_t st);
+                hipStream_t st, Fr* tmp = nullptr);
 }  // namespace shp

@@ -179,6 +179,9 @@ struct alignas(16) Fp {
     // Montgomery product a*b/R mod p. Operands may be any 256-bit values with a*b < p*R
     // (so raw, unreduced inputs such as ChaCha output are allowed against a reduced one).
     static SHP_HD Fp mul(const Fp& a, const Fp& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+        return mul_host64(a, b);
+#else
         uint32_t t[8];
         uint32_t t8 = 0;
 #pragma unroll
@@ -213,7 +216,47 @@ struct alignas(16) Fp {
         // still < 2p, and 2p < 2^256, so a single conditional subtraction is enough.
         r.reduce_once();
         return r;
+#endif
     }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // host path of the same CIOS product on 4 x u64 limbs (the driver's transcript / witness work)
+    static inline Fp mul_host64(const Fp& a, const Fp& b) {
+        typedef unsigned __int128 u128;
+        uint64_t A[4], Bv[4], P[4], t[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            A[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+            Bv[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+            P[i] = (uint64_t)PR::p(2 * i) | ((uint64_t)PR::p(2 * i + 1) << 32);
+        }
+        // -p^-1 mod 2^64 from the 32-bit constant by one Newton step
+        const uint64_t p0 = P[0];
+        uint64_t inv = (uint64_t)PR::INV;                // -p^-1 mod 2^32
+        inv = inv * (2 + p0 * inv);                      // x' = x(2 + p x) keeps x = -p^-1 and doubles the bits
+        for (int i = 0; i < 4; i++) {
+            u128 c = 0;
+            for (int j = 0; j < 4; j++) {
+                c += (u128)A[j] * Bv[i] + t[j];
+                t[j] = (uint64_t)c;
+                c >>= 64;
+            }
+            u128 top = (u128)t[4] + c;
+            uint64_t m = t[0] * inv;
+            c = ((u128)m * P[0] + t[0]) >> 64;
+            for (int j = 1; j < 4; j++) {
+                c += (u128)m * P[j] + t[j];
+                t[j - 1] = (uint64_t)c;
+                c >>= 64;
+            }
+            top += c;
+            t[3] = (uint64_t)top;
+            t[4] = (uint64_t)(top >> 64);
+        }
+        Fp r;
+        for (int i = 0; i < 4; i++) { r.l[2 * i] = (uint32_t)t[i]; r.l[2 * i + 1] = (uint32_t)(t[i] >> 32); }
+        r.reduce_once();
+        return r;
+    }
+#endif
     static SHP_HD Fp sqr(const Fp& a) { return mul(a, a); }
 
     SHP_HD Fp operator+(const Fp& b) const { return add(*this, b); }

@@ -20,8 +20,7 @@
 //   * sum_b b * B_b: per-thread running sums over g buckets, an LDS suffix scan and a tree.
 //   * The handful of final XYZZ sums are normalised on the host (needed there anyway for the
 //     Keccak transcript).
-#include "ctx.hpp"
-#include "curve.cuh"
+#include "engine.hpp"
 
 namespace shp {
 
@@ -277,17 +276,6 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_reduce_kernel(const G1X* buck
 
 using namespace shp;
 
-struct shp_msm {
-    shp_ctx* ctx = nullptr;
-    size_t n = 0;
-    uint32_t c = 0, W = 0, NB = 0;
-    G1Affine* d_table = nullptr;
-    DevBuf ws_cnt, ws_start, ws_entries, ws_pf, ws_pl, ws_buckets, ws_out;
-    std::vector<G1X> h_out;
-    uint64_t last_adds = 0, last_bytes = 0;
-    std::mutex mu;
-};
-
 static uint32_t pick_window(size_t n) {
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
@@ -316,27 +304,26 @@ static void msm_build(shp_ctx* ctx, const G1Affine* d_bases, size_t n, uint32_t 
     *out = m.release();
 }
 
-void msm_run(shp_msm* m, const Fr* d_scalars, size_t n_scalars, size_t stride, uint32_t batch, G1Affine* h_out,
-             hipStream_t st) {
+void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n_scalars, size_t stride,
+                uint32_t batch, G1Affine* h_out, hipStream_t st) {
     SHP_REQUIRE(m && d_scalars && h_out, SHP_ERR_INVALID_ARG, "msm: null argument");
     SHP_REQUIRE(n_scalars <= m->n, SHP_ERR_INVALID_ARG, "msm: more scalars than bases");
     if (batch == 0) return;
-    std::lock_guard<std::mutex> g(m->mu);
     const uint32_t NB = m->NB, W = m->W;
     const size_t entries_stride = n_scalars * W;
     const uint32_t T = entries_stride >= ((size_t)1 << 22) ? 64 : 16;
     const uint32_t chunks = ceil_div(entries_stride, T);
-    m->ws_cnt.reserve((size_t)batch * (NB + 2) * 4);
-    m->ws_start.reserve((size_t)batch * (NB + 2) * 4);
-    m->ws_entries.reserve((size_t)batch * entries_stride * 4);
-    m->ws_pf.reserve((size_t)batch * chunks * sizeof(Partial));
-    m->ws_pl.reserve((size_t)batch * chunks * sizeof(Partial));
-    m->ws_buckets.reserve((size_t)batch * (NB + 1) * sizeof(G1X));
-    m->ws_out.reserve((size_t)batch * sizeof(G1X));
-    uint32_t* cnt = m->ws_cnt.as<uint32_t>();
-    uint32_t* start = m->ws_start.as<uint32_t>();
-    uint32_t* entries = m->ws_entries.as<uint32_t>();
-    G1X* buckets = m->ws_buckets.as<G1X>();
+    ws.cnt.reserve((size_t)batch * (NB + 2) * 4);
+    ws.start.reserve((size_t)batch * (NB + 2) * 4);
+    ws.entries.reserve((size_t)batch * entries_stride * 4);
+    ws.pf.reserve((size_t)batch * chunks * sizeof(Partial));
+    ws.pl.reserve((size_t)batch * chunks * sizeof(Partial));
+    ws.buckets.reserve((size_t)batch * (NB + 1) * sizeof(G1X));
+    ws.out.reserve((size_t)batch * sizeof(G1X));
+    uint32_t* cnt = ws.cnt.as<uint32_t>();
+    uint32_t* start = ws.start.as<uint32_t>();
+    uint32_t* entries = ws.entries.as<uint32_t>();
+    G1X* buckets = ws.buckets.as<G1X>();
 
     SHP_HIP(hipMemsetAsync(cnt, 0, (size_t)batch * (NB + 2) * 4, st));
     dim3 gd(ceil_div(n_scalars, MSM_THREADS), batch);
@@ -348,28 +335,28 @@ void msm_run(shp_msm* m, const Fr* d_scalars, size_t n_scalars, size_t stride, u
                        W, NB, cnt, start, entries, entries_stride);
     SHP_HIP(hipMemsetAsync(buckets, 0, (size_t)batch * (NB + 1) * sizeof(G1X), st));
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(ceil_div(chunks, MSM_THREADS), batch), dim3(MSM_THREADS), 0, st,
-                       m->d_table, entries, entries_stride, start, NB, T, chunks, buckets, m->ws_pf.as<Partial>(),
-                       m->ws_pl.as<Partial>());
+                       m->d_table, entries, entries_stride, start, NB, T, chunks, buckets, ws.pf.as<Partial>(),
+                       ws.pl.as<Partial>());
     hipLaunchKernelGGL(msm_fixup_kernel, dim3(ceil_div(NB, MSM_THREADS), batch), dim3(MSM_THREADS), 0, st, start, NB, T,
-                       chunks, buckets, m->ws_pf.as<Partial>(), m->ws_pl.as<Partial>());
-    hipLaunchKernelGGL(msm_reduce_kernel, dim3(batch), dim3(MSM_THREADS), 0, st, buckets, NB, m->ws_out.as<G1X>());
+                       chunks, buckets, ws.pf.as<Partial>(), ws.pl.as<Partial>());
+    hipLaunchKernelGGL(msm_reduce_kernel, dim3(batch), dim3(MSM_THREADS), 0, st, buckets, NB, ws.out.as<G1X>());
     SHP_HIP(hipGetLastError());
-    m->h_out.resize(batch);
-    SHP_HIP(hipMemcpyAsync(m->h_out.data(), m->ws_out.p, (size_t)batch * sizeof(G1X), hipMemcpyDeviceToHost, st));
-    std::vector<uint32_t> totals(batch);
-    for (uint32_t b = 0; b < batch; b++)
-        SHP_HIP(hipMemcpyAsync(&totals[b], start + (size_t)b * (NB + 2) + NB + 1, 4, hipMemcpyDeviceToHost, st));
+    ws.h_out.resize(batch);
+    ws.h_totals.resize(batch);
+    SHP_HIP(hipMemcpyAsync(ws.h_out.data(), ws.out.p, (size_t)batch * sizeof(G1X), hipMemcpyDeviceToHost, st));
+    SHP_HIP(hipMemcpy2DAsync(ws.h_totals.data(), 4, start + NB + 1, (size_t)(NB + 2) * 4, 4, batch,
+                             hipMemcpyDeviceToHost, st));
     SHP_HIP(hipStreamSynchronize(st));
     // host normalisation with one shared inversion (Montgomery's trick over ZZZ)
     std::vector<Fq> pre(batch);
     Fq acc = Fq::one();
     for (uint32_t b = 0; b < batch; b++) {
         pre[b] = acc;
-        if (!m->h_out[b].is_inf()) acc = acc * m->h_out[b].zzz;
+        if (!ws.h_out[b].is_inf()) acc = acc * ws.h_out[b].zzz;
     }
     Fq inv = Fq::inv(acc);
     for (uint32_t b = batch; b-- > 0;) {
-        const G1X& p = m->h_out[b];
+        const G1X& p = ws.h_out[b];
         if (p.is_inf()) { h_out[b].x = Fq::zero(); h_out[b].y = Fq::zero(); continue; }
         Fq zi = inv * pre[b];
         inv = inv * p.zzz;
@@ -377,9 +364,16 @@ void msm_run(shp_msm* m, const Fr* d_scalars, size_t n_scalars, size_t stride, u
         h_out[b].x = p.x * zz_inv;
         h_out[b].y = p.y * zi;
     }
-    m->last_adds = 0;
-    for (uint32_t b = 0; b < batch; b++) m->last_adds += totals[b];
-    m->last_bytes = (uint64_t)batch * n_scalars * 32 + (uint64_t)n_scalars * 64;
+    ws.last_adds = 0;
+    for (uint32_t b = 0; b < batch; b++) ws.last_adds += ws.h_totals[b];
+    ws.last_bytes = (uint64_t)batch * n_scalars * 32 + (uint64_t)n_scalars * 64;
+}
+
+void msm_run(shp_msm* m, const Fr* d_scalars, size_t n_scalars, size_t stride, uint32_t batch, G1Affine* h_out,
+             hipStream_t st) {
+    SHP_REQUIRE(m, SHP_ERR_INVALID_ARG, "msm: null plan");
+    std::lock_guard<std::mutex> g(m->mu);
+    msm_run_ws(m, m->ws, d_scalars, n_scalars, stride, batch, h_out, st);
 }
 
 extern "C" {
@@ -409,8 +403,7 @@ int32_t shp_msm_destroy(shp_msm* m) {
     return guarded([&] {
         if (!m) return;
         if (m->d_table) (void)hipFree(m->d_table);
-        m->ws_cnt.release(); m->ws_start.release(); m->ws_entries.release(); m->ws_pf.release();
-        m->ws_pl.release(); m->ws_buckets.release(); m->ws_out.release();
+        m->ws.release();
         delete m;
     });
 }
@@ -427,8 +420,8 @@ int32_t shp_msm_g1(shp_msm* m, const void* d_scalars, size_t n_scalars, size_t s
 int32_t shp_msm_last_stats(shp_msm* m, uint64_t* point_adds, uint64_t* bytes) {
     return guarded([&] {
         SHP_REQUIRE(m, SHP_ERR_INVALID_ARG, "msm: null plan");
-        if (point_adds) *point_adds = m->last_adds;
-        if (bytes) *bytes = m->last_bytes;
+        if (point_adds) *point_adds = m->ws.last_adds;
+        if (bytes) *bytes = m->ws.last_bytes;
     });
 }
 

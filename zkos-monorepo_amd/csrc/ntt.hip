@@ -239,7 +239,7 @@ const NttTables& ntt_tables_for(shp_ctx* ctx, uint32_t log_n) {
 }
 
 void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_t batch, const NttOpts& o,
-                hipStream_t st) {
+                hipStream_t st, Fr* tmp_in) {
     SHP_REQUIRE(log_n >= 1 && log_n <= 27, SHP_ERR_INVALID_ARG, "ntt: log_n out of range [1,27]");
     if (batch == 0) return;
     const NttTables& T = ntt_tables_for(ctx, log_n);
@@ -261,8 +261,8 @@ void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_
         digits[1] = (log_n - digits[2]) / 2;
         digits[0] = log_n - digits[1] - digits[2];
     }
-    Fr* tmp = nullptr;
-    if (P > 1) {
+    Fr* tmp = tmp_in;
+    if (P > 1 && !tmp) {
         std::lock_guard<std::mutex> g(ctx->mu);
         ctx->ntt_tmp.reserve((size_t)batch * N * sizeof(Fr));
         tmp = ctx->ntt_tmp.as<Fr>();

@@ -1,0 +1,563 @@
+// Device kernels of the PLONK prover (halo2 create_proof phases P3-P13):
+// expression-program interpreter, grand products, lookup permutation, quotient terms,
+// evaluations and the evaluation-form SHPLONK quotients.  Everything is element-wise or a
+// single-workgroup scan over n <= 2^16 rows: latency-, not bandwidth-bound at k = 13, so the
+// design goal is few launches and no host round trips inside a phase.
+#pragma once
+#include "engine.hpp"
+#include "hostcrypto.hpp"
+#include "plan.hpp"
+
+namespace shp {
+
+__device__ __forceinline__ Fr ld(const Fr* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void st(Fr* p, const Fr& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// ------------------------------------------------------------------ expression programs
+// One lane per row.  The plan's three-address program runs over "slots" kept in LDS as
+// [slot][limb][lane] (lane-contiguous dwords: conflict free); the instruction stream is wave
+// uniform, so the opcode switch never diverges.  OUT folds into acc = acc * mult + value:
+// mult = y for the gate part of the quotient, theta for lookup compression.
+struct ProgArgs {
+    const Instr* prog;
+    uint32_t n_instr, nslots;
+    const Fr* consts;
+    const Query* adv_q;
+    const Query* fix_q;
+    const Query* inst_q;
+    const Fr* adv_base; size_t adv_stride;
+    const Fr* fix_base; size_t fix_stride;
+    const Fr* inst_base;
+    uint32_t size_mask, rot_step;
+    Fr mult;
+    const Fr* acc_in;
+    Fr* out;
+};
+
+constexpr int PROG_THREADS = 64;
+
+__global__ __launch_bounds__(PROG_THREADS) void prog_fold_kernel(ProgArgs a) {
+    extern __shared__ uint32_t slots[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t row = blockIdx.x * PROG_THREADS + tid;
+    auto get = [&](uint32_t s) {
+        Fr v;
+#pragma unroll
+        for (int l = 0; l < 8; l++) v.l[l] = slots[(s * 8 + l) * PROG_THREADS + tid];
+        return v;
+    };
+    auto put = [&](uint32_t s, const Fr& v) {
+#pragma unroll
+        for (int l = 0; l < 8; l++) slots[(s * 8 + l) * PROG_THREADS + tid] = v.l[l];
+    };
+    Fr acc = a.acc_in ? ld(a.acc_in + row) : Fr::zero();
+    for (uint32_t i = 0; i < a.n_instr; i++) {
+        const Instr in = a.prog[i];
+        switch (in.op) {
+            case OP_CONST: put(in.dst, ld(a.consts + in.a)); break;
+            case OP_ADV: {
+                Query q = a.adv_q[in.a];
+                uint32_t r = (row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask;
+                put(in.dst, ld(a.adv_base + (size_t)q.col * a.adv_stride + r));
+                break;
+            }
+            case OP_FIX: {
+                Query q = a.fix_q[in.a];
+                uint32_t r = (row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask;
+                put(in.dst, ld(a.fix_base + (size_t)q.col * a.fix_stride + r));
+                break;
+            }
+            case OP_INST: {
+                Query q = a.inst_q[in.a];
+                uint32_t r = (row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask;
+                put(in.dst, ld(a.inst_base + r));
+                break;
+            }
+            case OP_ADD: put(in.dst, get(in.a) + get(in.b)); break;
+            case OP_SUB: put(in.dst, get(in.a) - get(in.b)); break;
+            case OP_MUL: put(in.dst, get(in.a) * get(in.b)); break;
+            case OP_NEG: put(in.dst, Fr::neg(get(in.a))); break;
+            case OP_OUT: acc = acc * a.mult + get(in.a); break;
+            default: break;
+        }
+    }
+    st(a.out + row, acc);
+}
+
+// ------------------------------------------------------------------ blinding stream
+__global__ void chacha_fr_kernel(const uint32_t* key8, uint64_t counter0, uint32_t count, Fr* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t key[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) key[j] = key8[j];
+    st(out + i, fr_draw(key, counter0 + i));
+}
+
+// ------------------------------------------------------------------ grand products
+constexpr int MAX_PERM_COLS = 64;
+struct PermArgs {
+    const Fr* col[MAX_PERM_COLS];       // per permutation column: values (lagrange) or coset
+    Fr dbeta[MAX_PERM_COLS];            // delta^ci * beta
+    const Fr* sigma;                    // [PC][size]
+    size_t sigma_stride;
+    const Fr* xs;                       // omega^i (lagrange) or zeta*omega_ext^i (extended)
+    uint32_t n_cols, chunk;
+    Fr beta, gamma;
+};
+
+// ratio numerators / denominators of permutation set s on the lagrange domain
+__global__ void perm_ratio_kernel(PermArgs a, uint32_t n, Fr* num, Fr* den) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = blockIdx.y;
+    if (i >= n) return;
+    Fr nu = Fr::one(), de = Fr::one();
+    Fr x = ld(a.xs + i);
+    uint32_t lo = s * a.chunk, hi = lo + a.chunk < a.n_cols ? lo + a.chunk : a.n_cols;
+    for (uint32_t c = lo; c < hi; c++) {
+        Fr v = ld(a.col[c] + i);
+        de = de * (a.beta * ld(a.sigma + (size_t)c * a.sigma_stride + i) + v + a.gamma);
+        nu = nu * (a.dbeta[c] * x + v + a.gamma);
+    }
+    st(num + (size_t)s * n + i, nu);
+    st(den + (size_t)s * n + i, de);
+}
+
+__global__ void lookup_ratio_kernel(const Fr* cin, const Fr* ctab, const Fr* pin, const Fr* ptab, size_t pstride,
+                                    uint32_t n, Fr beta, Fr gamma, Fr* num, Fr* den) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t l = blockIdx.y;
+    if (i >= n) return;
+    Fr nu = (ld(cin + (size_t)l * n + i) + beta) * (ld(ctab + (size_t)l * n + i) + gamma);
+    Fr de = (ld(pin + (size_t)l * pstride + i) + beta) * (ld(ptab + (size_t)l * pstride + i) + gamma);
+    st(num + (size_t)l * n + i, nu);
+    st(den + (size_t)l * n + i, de);
+}
+
+// block-wide multiplicative scans over one value per thread (Hillis-Steele in LDS)
+__device__ __forceinline__ Fr block_scan_fwd_excl(Fr v, Fr* sh, uint32_t t, uint32_t nt) {
+    sh[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < nt; off <<= 1) {
+        Fr x = sh[t];
+        if (t >= off) x = x * sh[t - off];
+        __syncthreads();
+        sh[t] = x;
+        __syncthreads();
+    }
+    Fr r = t ? sh[t - 1] : Fr::one();
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ Fr block_scan_bwd_excl(Fr v, Fr* sh, uint32_t t, uint32_t nt) {
+    sh[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < nt; off <<= 1) {
+        Fr x = sh[t];
+        if (t + off < nt) x = x * sh[t + off];
+        __syncthreads();
+        sh[t] = x;
+        __syncthreads();
+    }
+    Fr r = t + 1 < nt ? sh[t + 1] : Fr::one();
+    __syncthreads();
+    return r;
+}
+
+// z[0] = start, z[i+1] = z[i] * num[i] / den[i]; ONE field inversion per product (of the total
+// denominator): 1 / prod_{r<i} den_r = (prod_{r>=i} den_r) / prod_all.
+// block 0: the permutation sets, chained through z[usable]; block 1 + l: lookup l.
+// z_out[p] = zbase + p * zstride for product p in the order [perm sets..., lookups...].
+__global__ __launch_bounds__(1024) void grand_product_kernel(const Fr* num, const Fr* den, uint32_t n, uint32_t n_sets,
+                                                             uint32_t usable, uint32_t bf, Fr* zbase, size_t zstride,
+                                                             const Fr* blinds) {
+    __shared__ Fr sh[1024];
+    __shared__ Fr bc[2];
+    const uint32_t t = threadIdx.x, nt = blockDim.x;
+    const uint32_t per = n / nt;
+    const uint32_t first = blockIdx.x == 0 ? 0 : n_sets + blockIdx.x - 1;
+    const uint32_t count = blockIdx.x == 0 ? n_sets : 1;
+    Fr start = Fr::one();
+    for (uint32_t pi = 0; pi < count; pi++) {
+        const uint32_t p = first + pi;
+        const Fr* nu = num + (size_t)p * n;
+        const Fr* de = den + (size_t)p * n;
+        Fr* z = zbase + (size_t)p * zstride;
+        const uint32_t r0 = t * per;
+        Fr ln = Fr::one(), ldn = Fr::one();
+        for (uint32_t j = 0; j < per; j++) {
+            ln = ln * ld(nu + r0 + j);
+            ldn = ldn * ld(de + r0 + j);
+        }
+        Fr npre = block_scan_fwd_excl(ln, sh, t, nt);
+        Fr ssuf = block_scan_bwd_excl(ldn, sh, t, nt);
+        if (t == 0) bc[0] = Fr::inv(ldn * ssuf);
+        __syncthreads();
+        Fr inv_tot = bc[0];
+        Fr s = ssuf;
+        for (int j = (int)per - 1; j >= 0; j--) {
+            s = s * ld(de + r0 + j);
+            st(z + r0 + j, s);
+        }
+        Fr c = start * inv_tot * npre;
+        for (uint32_t j = 0; j < per; j++) {
+            Fr zi = c * ld(z + r0 + j);
+            st(z + r0 + j, zi);
+            if (r0 + j == usable) bc[1] = zi;
+            c = c * ld(nu + r0 + j);
+        }
+        __syncthreads();
+        start = bc[1];
+        if (t < bf) st(z + n - bf + t, ld(blinds + (size_t)p * bf + t));
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ lookup permutation
+// (halo2 lookup::prover::permute_expression_pair) -- all on device:
+// rank sort of the usable rows (n^2 / 2 comparisons are cheap at n = 2^13), then flags,
+// prefix sums and binary searches in one workgroup.
+__device__ __forceinline__ int raw_cmp(const Fr& a, const Fr& b) {
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        if (a.l[i] < b.l[i]) return -1;
+        if (a.l[i] > b.l[i]) return 1;
+    }
+    return 0;
+}
+
+__global__ void to_raw_kernel(const Fr* in, Fr* out, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) st(out + i, ld(in + i).to_raw());
+}
+
+// sorted[rank(i)] = raw[i]; blockIdx.y selects the array (stride `stride`)
+__global__ __launch_bounds__(256) void rank_sort_kernel(const Fr* raw, Fr* sorted, uint32_t u, size_t stride) {
+    __shared__ Fr tile[256];
+    const Fr* src = raw + (size_t)blockIdx.y * stride;
+    Fr* dst = sorted + (size_t)blockIdx.y * stride;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    Fr mine = i < u ? ld(src + i) : Fr::zero();
+    uint32_t rank = 0;
+    for (uint32_t base = 0; base < u; base += 256) {
+        uint32_t j = base + threadIdx.x;
+        __syncthreads();
+        if (j < u) tile[threadIdx.x] = ld(src + j);
+        __syncthreads();
+        uint32_t lim = u - base < 256 ? u - base : 256;
+        for (uint32_t k = 0; k < lim; k++) {
+            int c = raw_cmp(tile[k], mine);
+            rank += (c < 0 || (c == 0 && base + k < i)) ? 1u : 0u;
+        }
+    }
+    if (i < u) st(dst + rank, mine);
+}
+
+__device__ __forceinline__ bool bsearch_raw(const Fr* arr, uint32_t count, const Fr& key) {
+    uint32_t lo = 0, hi = count;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        int c = raw_cmp(ld(arr + mid), key);
+        if (c == 0) return true;
+        if (c < 0) lo = mid + 1;
+        else hi = mid;
+    }
+    return false;
+}
+
+__device__ __forceinline__ uint32_t block_scan_u32_excl(uint32_t v, uint32_t* sh, uint32_t t, uint32_t nt, uint32_t* total) {
+    sh[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < nt; off <<= 1) {
+        uint32_t x = sh[t];
+        if (t >= off) x += sh[t - off];
+        __syncthreads();
+        sh[t] = x;
+        __syncthreads();
+    }
+    uint32_t r = t ? sh[t - 1] : 0;
+    *total = sh[nt - 1];
+    __syncthreads();
+    return r;
+}
+
+// a = sorted input (raw), tb = sorted table (raw); writes permuted input / table (Montgomery)
+// rows [0,u) and the blinding rows [u,n) of both; err[0] != 0 when the input is not in the table.
+__global__ __launch_bounds__(1024) void lookup_permute_kernel(const Fr* a_all, const Fr* tb_all, size_t sstride, uint32_t u,
+                                                              uint32_t n, Fr* pin_all, Fr* ptab_all, size_t pstride,
+                                                              uint32_t* scratch_all, const Fr* blinds, uint32_t* err) {
+    __shared__ uint32_t sh[1024];
+    const uint32_t l = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    const Fr* a = a_all + (size_t)l * sstride;
+    const Fr* tb = tb_all + (size_t)l * sstride;
+    Fr* pin = pin_all + (size_t)l * pstride;
+    Fr* ptab = ptab_all + (size_t)l * pstride;
+    uint32_t* rep = scratch_all + (size_t)l * n;        // rows of repeated inputs, ascending
+    const uint32_t per = (u + nt - 1) / nt;
+    const uint32_t r0 = t * per, r1 = r0 + per < u ? r0 + per : u;
+    // pass 1: count repeated input rows / kept table entries in my range
+    uint32_t nrep = 0, nkeep = 0;
+    for (uint32_t i = r0; i < r1; i++) {
+        Fr ai = ld(a + i);
+        bool first = i == 0 || raw_cmp(ld(a + i - 1), ai) != 0;
+        if (!first) nrep++;
+        else if (!bsearch_raw(tb, u, ai)) atomicAdd(err, 1u);
+        Fr ti = ld(tb + i);
+        bool tfirst = i == 0 || raw_cmp(ld(tb + i - 1), ti) != 0;
+        bool removed = tfirst && bsearch_raw(a, u, ti);
+        if (!removed) nkeep++;
+    }
+    uint32_t tot_rep, tot_keep;
+    uint32_t rep_off = block_scan_u32_excl(nrep, sh, t, nt, &tot_rep);
+    uint32_t keep_off = block_scan_u32_excl(nkeep, sh, t, nt, &tot_keep);
+    if (t == 0 && tot_rep != tot_keep) atomicAdd(err, 1u);
+    // pass 2: list the repeated rows; write first occurrences
+    uint32_t q = rep_off;
+    for (uint32_t i = r0; i < r1; i++) {
+        Fr ai = ld(a + i);
+        bool first = i == 0 || raw_cmp(ld(a + i - 1), ai) != 0;
+        Fr am = Fr::from_raw(ai);
+        st(pin + i, am);
+        if (first) st(ptab + i, am);
+        else rep[q++] = i;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // pass 3: leftover table entries (ascending) go to the repeated rows taken from the END
+    q = keep_off;
+    for (uint32_t i = r0; i < r1; i++) {
+        Fr ti = ld(tb + i);
+        bool tfirst = i == 0 || raw_cmp(ld(tb + i - 1), ti) != 0;
+        bool removed = tfirst && bsearch_raw(a, u, ti);
+        if (!removed) {
+            if (q < tot_rep) st(ptab + rep[tot_rep - 1 - q], Fr::from_raw(ti));
+            q++;
+        }
+    }
+    const uint32_t nb = n - u;
+    if (t < nb) {
+        st(pin + u + t, ld(blinds + (size_t)(2 * l) * nb + t));
+        st(ptab + u + t, ld(blinds + (size_t)(2 * l + 1) * nb + t));
+    }
+}
+
+// ------------------------------------------------------------------ quotient terms (extended domain)
+struct PermQArgs {
+    PermArgs p;                 // col = cosets, sigma = sigma cosets, xs = zeta * omega_ext^i
+    const Fr* pz;               // [n_sets][ne]
+    const Fr* l0; const Fr* l_last; const Fr* l_active;
+    uint32_t n_sets, mask, step;
+    int32_t rot_last;
+    Fr y;
+    Fr* h;
+};
+
+__global__ void perm_quotient_kernel(PermQArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t ne = (size_t)a.mask + 1;
+    Fr h = ld(a.h + i);
+    const Fr l0 = ld(a.l0 + i), ll = ld(a.l_last + i), la = ld(a.l_active + i);
+    const Fr one = Fr::one();
+    h = h * a.y + l0 * (one - ld(a.pz + i));
+    Fr zl = ld(a.pz + (size_t)(a.n_sets - 1) * ne + i);
+    h = h * a.y + ll * (Fr::sqr(zl) - zl);
+    const uint32_t ilast = (i + (uint32_t)(a.rot_last * (int32_t)a.step)) & a.mask;
+    for (uint32_t s = 1; s < a.n_sets; s++)
+        h = h * a.y + l0 * (ld(a.pz + (size_t)s * ne + i) - ld(a.pz + (size_t)(s - 1) * ne + ilast));
+    const uint32_t inext = (i + a.step) & a.mask;
+    const Fr x = ld(a.p.xs + i);
+    for (uint32_t s = 0; s < a.n_sets; s++) {
+        Fr left = ld(a.pz + (size_t)s * ne + inext), right = ld(a.pz + (size_t)s * ne + i);
+        uint32_t lo = s * a.p.chunk, hi = lo + a.p.chunk < a.p.n_cols ? lo + a.p.chunk : a.p.n_cols;
+        for (uint32_t c = lo; c < hi; c++) {
+            Fr v = ld(a.p.col[c] + i);
+            left = left * (a.p.beta * ld(a.p.sigma + (size_t)c * a.p.sigma_stride + i) + v + a.p.gamma);
+            right = right * (a.p.dbeta[c] * x + v + a.p.gamma);
+        }
+        h = h * a.y + la * (left - right);
+    }
+    st(a.h + i, h);
+}
+
+struct LookupQArgs {
+    const Fr* z; const Fr* pin; const Fr* ptab;       // cosets
+    const Fr* ain; const Fr* stab;                     // theta-compressed input / table on the coset
+    const Fr* l0; const Fr* l_last; const Fr* l_active;
+    uint32_t mask, step;
+    Fr y, beta, gamma;
+    Fr* h;
+};
+
+__global__ void lookup_quotient_kernel(LookupQArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr h = ld(a.h + i);
+    const Fr l0 = ld(a.l0 + i), ll = ld(a.l_last + i), la = ld(a.l_active + i);
+    const Fr z = ld(a.z + i), ap = ld(a.pin + i), sp = ld(a.ptab + i);
+    const uint32_t inext = (i + a.step) & a.mask, iprev = (i - a.step) & a.mask;
+    h = h * a.y + l0 * (Fr::one() - z);
+    h = h * a.y + ll * (Fr::sqr(z) - z);
+    Fr lhs = ld(a.z + inext) * (ap + a.beta) * (sp + a.gamma);
+    Fr rhs = z * (ld(a.ain + i) + a.beta) * (ld(a.stab + i) + a.gamma);
+    h = h * a.y + la * (lhs - rhs);
+    Fr d = ap - sp;
+    h = h * a.y + l0 * d;
+    h = h * a.y + la * d * (ap - ld(a.pin + iprev));
+    st(a.h + i, h);
+}
+
+__global__ void scale_periodic_kernel(Fr* h, const Fr* t_inv, uint32_t period_mask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    st(h + i, ld(h + i) * ld(t_inv + (i & period_mask)));
+}
+
+// ------------------------------------------------------------------ evaluations
+// pw[p][i] = point_p^i
+__global__ void powers_kernel(const Fr* points, uint32_t n, uint32_t per, Fr* pw) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t p = blockIdx.y;
+    uint32_t i0 = t * per;
+    if (i0 >= n) return;
+    Fr x = ld(points + p);
+    Fr acc = Fr::pow_u64(x, i0);
+    Fr* dst = pw + (size_t)p * n;
+    for (uint32_t j = 0; j < per && i0 + j < n; j++) {
+        st(dst + i0 + j, acc);
+        acc = acc * x;
+    }
+}
+
+struct EvalJob { const Fr* poly; uint32_t point; uint32_t pad; };
+
+// out[job] = sum_i poly[i] * pw[point][i]
+__global__ __launch_bounds__(256) void eval_kernel(const EvalJob* jobs, const Fr* pw, uint32_t n, Fr* out) {
+    __shared__ Fr sh[256];
+    const EvalJob jb = jobs[blockIdx.x];
+    const Fr* w = pw + (size_t)jb.point * n;
+    Fr acc = Fr::zero();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) acc = acc + ld(jb.poly + i) * ld(w + i);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st(out + blockIdx.x, sh[0]);
+}
+
+// hx = sum_i x^(n i) piece_i  (Horner over the quotient pieces)
+__global__ void combine_pieces_kernel(const Fr* pieces, uint32_t n, uint32_t count, Fr xn, Fr* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr acc = Fr::zero();
+    for (int p = (int)count - 1; p >= 0; p--) acc = acc * xn + ld(pieces + (size_t)p * n + i);
+    st(out + i, acc);
+}
+
+// ------------------------------------------------------------------ SHPLONK in evaluation form
+// Every opened polynomial has degree < n, so the quotients (f_i - R_i) / Z_i and
+// L / (diff_0 (X - mu)) are fixed by their values on the size-n domain: they are formed
+// point-wise and committed with the Lagrange-basis SRS -- the same group elements as the
+// textbook coefficient-form division, with no polynomial division and no extra NTT.
+constexpr int MAX_SETS = 8, MAX_SET_POLYS = 96, MAX_SET_ROTS = 4, MAX_POINTS = 8;
+
+struct LincombArgs {
+    const Fr* poly[MAX_SET_POLYS];
+    Fr coef[MAX_SET_POLYS];
+    uint32_t count;
+};
+__global__ void lincomb_kernel(const LincombArgs* args, uint32_t n, Fr* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const LincombArgs& a = args[blockIdx.y];
+    if (i >= n) return;
+    Fr acc = Fr::zero();
+    for (uint32_t j = 0; j < a.count; j++) acc = acc + a.coef[j] * ld(a.poly[j] + i);
+    st(out + (size_t)blockIdx.y * n + i, acc);
+}
+
+// d[p][i] = omega^i - point_p
+__global__ void point_diff_kernel(const Fr* omegas, const Fr* points, uint32_t n, Fr* d) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st(d + (size_t)blockIdx.y * n + i, ld(omegas + i) - ld(points + blockIdx.y));
+}
+
+// out[i] = 1 / in[i] over blockDim.x * per contiguous elements per workgroup, with ONE Fermat
+// inversion per workgroup: inv(a_j) = inv(total) * (product of everything else)
+__global__ __launch_bounds__(1024) void batch_invert_kernel(const Fr* in, Fr* out, uint32_t per) {
+    __shared__ Fr sh[1024];
+    __shared__ Fr bc;
+    const uint32_t t = threadIdx.x, nt = blockDim.x;
+    const Fr* bi = in + ((size_t)blockIdx.x * nt + t) * per;
+    Fr* bo = out + ((size_t)blockIdx.x * nt + t) * per;
+    Fr prod = Fr::one();
+    for (uint32_t j = 0; j < per; j++) prod = prod * ld(bi + j);
+    Fr pre = block_scan_fwd_excl(prod, sh, t, nt);
+    Fr suf = block_scan_bwd_excl(prod, sh, t, nt);
+    if (t == 0) bc = Fr::inv(prod * suf);
+    __syncthreads();
+    const Fr outer = bc * pre * suf;             // 1 / (product of my chunk)
+    Fr run = Fr::one();
+    for (int j = (int)per - 1; j >= 0; j--) {
+        st(bo + j, run);                         // product of my elements to the right of j
+        run = run * ld(bi + j);
+    }
+    Fr left = outer;
+    for (uint32_t j = 0; j < per; j++) {
+        st(bo + j, left * ld(bo + j));
+        left = left * ld(bi + j);
+    }
+}
+
+struct ShplonkArgs {
+    uint32_t n_sets;
+    uint32_t n_rots[MAX_SETS];
+    uint32_t rot_pt[MAX_SETS][MAX_SET_ROTS];     // index of the set's points in `dinv`
+    Fr rcoef[MAX_SETS][MAX_SET_ROTS];            // R_i coefficients, low to high
+    Fr coef[MAX_SETS];                           // nu^i  (W)   |  nu^i diff_i / diff_0  (W')
+    Fr c0, c1;                                   // W': sum_i coef_i R_i(mu), Z_T(mu) / diff_0
+    const Fr* f;                                 // [n_sets][n] combined set polynomials (values)
+    const Fr* dinv;                              // [points][n] 1 / (omega^r - point)
+    const Fr* omegas;                            // omega^r
+    const Fr* w;                                 // W values (W' only)
+    const Fr* minv;                              // 1 / (omega^r - mu) (W' only)
+};
+
+// W(omega^r) = sum_i nu^i (f_i - R_i)(omega^r) / Z_i(omega^r)
+__global__ void shplonk_w_kernel(const ShplonkArgs* ap, uint32_t n, Fr* out) {
+    const ShplonkArgs& a = *ap;
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    Fr acc = Fr::zero();
+    for (uint32_t i = 0; i < a.n_sets; i++) {
+        Fr rv = a.rcoef[i][0];
+        for (uint32_t t = 1; t < a.n_rots[i]; t++) rv = rv + a.rcoef[i][t] * ld(a.omegas + (((uint64_t)r * t) & (n - 1)));
+        Fr v = ld(a.f + (size_t)i * n + r) - rv;
+        for (uint32_t t = 0; t < a.n_rots[i]; t++) v = v * ld(a.dinv + (size_t)a.rot_pt[i][t] * n + r);
+        acc = acc + a.coef[i] * v;
+    }
+    st(out + r, acc);
+}
+
+// W'(omega^r) = (sum_i coef_i f_i(omega^r) - c0 - c1 W(omega^r)) / (omega^r - mu)
+__global__ void shplonk_wp_kernel(const ShplonkArgs* ap, uint32_t n, Fr* out) {
+    const ShplonkArgs& a = *ap;
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    Fr acc = Fr::zero();
+    for (uint32_t i = 0; i < a.n_sets; i++) acc = acc + a.coef[i] * ld(a.f + (size_t)i * n + r);
+    acc = acc - a.c0 - a.c1 * ld(a.w + r);
+    st(out + r, acc * ld(a.minv + r));
+}
+
+}  // namespace shp
