@@ -120,6 +120,10 @@ int32_t shp_srs_from_halo2_raw(shp_ctx* ctx, const uint8_t* bytes, size_t len, s
 /* Params from explicit tables (e.g. a synthetic SRS); g2 / s_g2 may be NULL. */
 int32_t shp_srs_from_parts(shp_ctx* ctx, uint32_t k, const void* h_g, const void* h_g_lagrange,
                            const uint8_t* g2_128, const uint8_t* s_g2_128, shp_srs** out);
+/* generate_setup_params(k, rng) (/root/reference/crates/halo2-verifier/src/generator.rs:32-40): an SRS
+ * with the KNOWN trapdoor tau (32-byte LE canonical): g[i] = tau^i G, g_lagrange by group FFT.  For
+ * tests and benchmarks only -- the reference's real k=13 ptau file is not shipped. No G2 part. */
+int32_t shp_srs_synthetic(shp_ctx* ctx, uint32_t k, const uint8_t tau_le32[32], shp_srs** out);
 int32_t shp_srs_destroy(shp_srs* srs);
 int32_t shp_srs_k(const shp_srs* srs, uint32_t* k);
 /* copies of the tables / G2 elements back to the host (Params::get_g, g2, s_g2) */

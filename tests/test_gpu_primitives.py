@@ -142,6 +142,15 @@ def test_srs_from_ptau_on_gpu_equals_raw(shp, oracle, gpu_ctx):
         shp.Params.read_ptau(gpu_ctx, b"\x00" * 100)
 
 
+def test_srs_synthetic_matches_oracle(shp, oracle, gpu_ctx):
+    tau = 0x1234567890ABCDEF1234567890ABCDEF55
+    p = shp.Params.synthetic(gpu_ctx, 9, tau)
+    o = oracle.srs_synthetic(9, tau)
+    assert np.array_equal(p.get_g(shp.BASIS_MONOMIAL), o.g)
+    assert np.array_equal(p.get_g(shp.BASIS_LAGRANGE), o.g_lagrange)
+    p.close()
+
+
 @pytest.mark.parametrize("n,window", [(1, 0), (5, 0), (100, 7), (2048, 0), (2048, 12), (8192, 0)])
 def test_msm_matches_oracle(shp, oracle, gpu_ctx, n, window):
     osrs = oracle.srs_synthetic(13, 0xDEADBEEFCAFE1234567)

@@ -47,6 +47,10 @@ def lib():
         if not os.path.exists(_SO):
             raise ShpError(-1, f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "-- the product path has no CPU fallback")
+        # torch (plumbing: device memory, streams) bundles its own HIP runtime and loads it RTLD_GLOBAL;
+        # importing it FIRST makes libshielder_hip resolve its hip* symbols to that same runtime
+        # instance, so stream handles and device pointers are interchangeable between the two.
+        import torch  # noqa: F401
         _lib = C.CDLL(_SO)
         _lib.shp_last_error.restype = C.c_char_p
         _lib.shp_version.restype = C.c_char_p
@@ -219,6 +223,13 @@ class Params:
                                         gl.ctypes.data_as(C.c_void_p) if gl is not None else None,
                                         C.c_char_p(g2) if g2 else None, C.c_char_p(s_g2) if s_g2 else None,
                                         C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def synthetic(cls, ctx, k, tau: int):
+        """generate_setup_params stand-in: SRS with a known trapdoor (tests / benchmarks)"""
+        h = C.c_void_p()
+        _check(lib().shp_srs_synthetic(ctx.h, C.c_uint32(k), C.c_char_p(int(tau).to_bytes(32, "little")), C.byref(h)))
         return cls(ctx, h)
 
     def get_g(self, basis=BASIS_MONOMIAL):

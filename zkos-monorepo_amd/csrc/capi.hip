@@ -81,6 +81,15 @@ static void g1_lagrange_from_monomial(shp_ctx* ctx, const G1Affine* d_g, G1Affin
     SHP_HIP(e2);
 }
 
+// synthetic SRS: g[i] = tau^i * G, one lane per power (254-bit double-and-add on the generator)
+__global__ void srs_powers_kernel(const Fr* scalars_raw, G1Affine* out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1X g;
+    g.x = Fq::from_u64(1); g.y = Fq::from_u64(2); g.zz = Fq::one(); g.zzz = Fq::one();
+    out[i] = g1_to_affine(g1_mul_raw(g, scalars_raw[i]));
+}
+
 static bool fq_canonical(const Fq& v) { return !v.geq_p(); }
 static bool on_curve(const G1Affine& p) {
     if (p.is_inf()) return true;
@@ -301,6 +310,37 @@ int32_t shp_srs_from_parts(shp_ctx* ctx, uint32_t k, const void* h_g, const void
             throw;
         }
         *out = s;
+    });
+}
+
+int32_t shp_srs_synthetic(shp_ctx* ctx, uint32_t k, const uint8_t tau_le32[32], shp_srs** out) {
+    return guarded([&] {
+        SHP_REQUIRE(ctx && tau_le32 && out, SHP_ERR_INVALID_ARG, "srs_synthetic: null argument");
+        SHP_REQUIRE(k >= 1 && k <= 20, SHP_ERR_INVALID_ARG, "srs_synthetic: k out of range");
+        Fr raw;
+        memcpy(raw.l, tau_le32, 32);
+        SHP_REQUIRE(!raw.geq_p(), SHP_ERR_FORMAT, "srs_synthetic: tau is not a canonical field element");
+        const Fr tau = Fr::from_raw(raw);
+        const uint32_t n = 1u << k;
+        std::vector<Fr> pw(n);
+        Fr acc = Fr::one();
+        for (uint32_t i = 0; i < n; i++) { pw[i] = acc.to_raw(); acc = acc * tau; }
+        Fr* d_s = nullptr;
+        G1Affine* d_g = nullptr;
+        SHP_HIP(hipMalloc(&d_s, (size_t)n * sizeof(Fr)));
+        SHP_HIP(hipMalloc(&d_g, (size_t)n * sizeof(G1Affine)));
+        std::vector<G1Affine> g(n);
+        hipError_t e = hipMemcpy(d_s, pw.data(), (size_t)n * sizeof(Fr), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(srs_powers_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, ctx->stream, d_s, d_g, n);
+            e = hipStreamSynchronize(ctx->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpy(g.data(), d_g, (size_t)n * sizeof(G1Affine), hipMemcpyDeviceToHost);
+        (void)hipFree(d_s);
+        (void)hipFree(d_g);
+        SHP_HIP(e);
+        int32_t rc = shp_srs_from_parts(ctx, k, g.data(), nullptr, nullptr, nullptr, out);
+        SHP_REQUIRE(rc == SHP_OK, rc, shp_last_error());
     });
 }
 
