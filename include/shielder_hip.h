@@ -161,6 +161,12 @@ int32_t shp_prover_destroy(shp_prover* p);
 int32_t shp_prove(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, const uint8_t seed[32],
                   uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* instances_le32,
                   size_t instances_cap);
+/* HIP-event timing of the lane's kernel launches, on the stream they run on: enable (resets the
+ * counters), prove, then read entry `index` (0 .. until SHP_ERR_INVALID_ARG): kernel family name,
+ * number of launches, summed duration. */
+int32_t shp_prover_profile(shp_prover* p, int32_t enable);
+int32_t shp_prover_profile_read(shp_prover* p, uint32_t index, const char** name, uint64_t* launches,
+                                double* total_ms);
 /* poseidon::off_circuit::hash on the host (shielder_bindings/src/hash.rs:17-26): 32-byte LE canonical */
 int32_t shp_poseidon2_hash_host(const uint8_t* inputs_le32, uint32_t arity, uint8_t out_le32[32]);
 

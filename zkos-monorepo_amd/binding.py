@@ -316,6 +316,19 @@ class Prover:
         ins = [int.from_bytes(inst.raw[32 * i:32 * i + 32], "little") for i in range(self.pk.n_instances)]
         return proof.raw[:plen.value], ins
 
+    def profile(self, enable=True):
+        _check(lib().shp_prover_profile(self.h, C.c_int32(1 if enable else 0)))
+
+    def profile_read(self):
+        """{kernel family: (launches, total_ms)} measured with HIP events on the lane's stream"""
+        out = {}
+        for i in range(64):
+            name, cnt, ms = C.c_char_p(), C.c_uint64(), C.c_double()
+            if lib().shp_prover_profile_read(self.h, C.c_uint32(i), C.byref(name), C.byref(cnt), C.byref(ms)) != SHP_OK:
+                break
+            out[name.value.decode()] = (cnt.value, ms.value)
+        return out
+
     def close(self):
         if self.h:
             lib().shp_prover_destroy(self.h)

@@ -5,8 +5,59 @@
 
 namespace shp {
 
+// Optional HIP-event timing of individual kernel launches on the stream they run on (bench.py's
+// `roofline` object needs the dominant kernel's average launch duration measured live).
+enum KernelId {
+    KID_MSM_DIGITS = 0, KID_MSM_ACCUMULATE, KID_MSM_FIXUP, KID_MSM_REDUCE, KID_NTT, KID_PROG, KID_GRAND_PRODUCT,
+    KID_RANK_SORT, KID_BATCH_INVERT, KID_COUNT
+};
+static const char* const KERNEL_NAMES[KID_COUNT] = {"msm_digits", "msm_accumulate", "msm_fixup", "msm_reduce", "ntt_pass",
+                                                    "prog_fold", "grand_product", "rank_sort", "batch_invert"};
+struct KernelTimers {
+    bool enabled = false;
+    struct Rec { int id; hipEvent_t a, b; };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms[KID_COUNT] = {0};
+    uint64_t launches[KID_COUNT] = {0};
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        SHP_HIP(hipEventCreate(&e));
+        return e;
+    }
+    void begin(int id, hipStream_t st) {
+        if (!enabled) return;
+        Rec r{id, get(), get()};
+        SHP_HIP(hipEventRecord(r.a, st));
+        pending.push_back(r);
+    }
+    void end(hipStream_t st) {
+        if (!enabled) return;
+        SHP_HIP(hipEventRecord(pending.back().b, st));
+    }
+    // call after the stream has been synchronised
+    void collect() {
+        for (auto& r : pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { total_ms[r.id] += ms; launches[r.id]++; }
+            pool.push_back(r.a);
+            pool.push_back(r.b);
+        }
+        pending.clear();
+    }
+    void reset() {
+        for (int i = 0; i < KID_COUNT; i++) { total_ms[i] = 0; launches[i] = 0; }
+    }
+    ~KernelTimers() {
+        for (auto& r : pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
 // per-caller scratch of one MSM pipeline (a prover instance owns one per stream)
 struct MsmWorkspace {
+    KernelTimers* timers = nullptr;
     DevBuf cnt, start, entries, pf, pl, buckets, out;
     std::vector<G1X> h_out;
     std::vector<uint32_t> h_totals;

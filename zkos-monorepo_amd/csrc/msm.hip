@@ -325,21 +325,30 @@ void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n
     uint32_t* entries = ws.entries.as<uint32_t>();
     G1X* buckets = ws.buckets.as<G1X>();
 
+    KernelTimers none, *tm = ws.timers ? ws.timers : &none;
     SHP_HIP(hipMemsetAsync(cnt, 0, (size_t)batch * (NB + 2) * 4, st));
     dim3 gd(ceil_div(n_scalars, MSM_THREADS), batch);
+    tm->begin(KID_MSM_DIGITS, st);
     hipLaunchKernelGGL(msm_digits_kernel<false>, gd, dim3(MSM_THREADS), 0, st, d_scalars, n_scalars, stride, m->n, m->c,
                        W, NB, cnt, (const uint32_t*)nullptr, (uint32_t*)nullptr, entries_stride);
+    tm->end(st);
     hipLaunchKernelGGL(msm_scan_kernel, dim3(batch), dim3(MSM_THREADS), 0, st, cnt, start, NB);
     SHP_HIP(hipMemsetAsync(cnt, 0, (size_t)batch * (NB + 2) * 4, st));
     hipLaunchKernelGGL(msm_digits_kernel<true>, gd, dim3(MSM_THREADS), 0, st, d_scalars, n_scalars, stride, m->n, m->c,
                        W, NB, cnt, start, entries, entries_stride);
     SHP_HIP(hipMemsetAsync(buckets, 0, (size_t)batch * (NB + 1) * sizeof(G1X), st));
+    tm->begin(KID_MSM_ACCUMULATE, st);
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(ceil_div(chunks, MSM_THREADS), batch), dim3(MSM_THREADS), 0, st,
                        m->d_table, entries, entries_stride, start, NB, T, chunks, buckets, ws.pf.as<Partial>(),
                        ws.pl.as<Partial>());
+    tm->end(st);
+    tm->begin(KID_MSM_FIXUP, st);
     hipLaunchKernelGGL(msm_fixup_kernel, dim3(ceil_div(NB, MSM_THREADS), batch), dim3(MSM_THREADS), 0, st, start, NB, T,
                        chunks, buckets, ws.pf.as<Partial>(), ws.pl.as<Partial>());
+    tm->end(st);
+    tm->begin(KID_MSM_REDUCE, st);
     hipLaunchKernelGGL(msm_reduce_kernel, dim3(batch), dim3(MSM_THREADS), 0, st, buckets, NB, ws.out.as<G1X>());
+    tm->end(st);
     SHP_HIP(hipGetLastError());
     ws.h_out.resize(batch);
     ws.h_totals.resize(batch);
@@ -347,6 +356,7 @@ void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n
     SHP_HIP(hipMemcpy2DAsync(ws.h_totals.data(), 4, start + NB + 1, (size_t)(NB + 2) * 4, 4, batch,
                              hipMemcpyDeviceToHost, st));
     SHP_HIP(hipStreamSynchronize(st));
+    tm->collect();
     // host normalisation with one shared inversion (Montgomery's trick over ZZZ)
     std::vector<Fq> pre(batch);
     Fq acc = Fq::one();

@@ -197,6 +197,8 @@ struct shp_prover {
     hipStream_t st = nullptr;
     bool own_stream = false;
     MsmWorkspace msm_ws;
+    KernelTimers timers;
+    uint64_t proofs_done = 0;
     // device workspace
     Fr *vals = nullptr, *polys = nullptr, *cos = nullptr;     // [NV + 1][n | n | ne]  (+1 = instance column)
     Fr *cin = nullptr, *ctab = nullptr;                        // [L][n] compressed lookup input / table
@@ -265,6 +267,7 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->blinds = pr->dalloc<Fr>((size_t)(S + L + 2 * L) * (P.bf + 1) + 64);
     pr->ntt_tmp = pr->dalloc<Fr>((size_t)(NV + 1) * ne);
     pr->key = pr->dalloc<uint32_t>(8);
+    pr->msm_ws.timers = &pr->timers;
     *out = pr.release();
 }
 
@@ -462,8 +465,10 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
             hipLaunchKernelGGL(to_raw_kernel, dim3(ceil_div(u, 256)), dim3(256), 0, st, pr->ctab + (size_t)l * n,
                                pr->sort_raw + (size_t)(2 * l + 1) * n, u);
         }
+        pr->timers.begin(KID_RANK_SORT, st);
         hipLaunchKernelGGL(rank_sort_kernel, dim3(ceil_div(u, 256), 2 * L), dim3(256), 0, st, pr->sort_raw, pr->sort_out, u,
                            (size_t)n);
+        pr->timers.end(st);
         hb.clear();
         for (uint32_t l = 0; l < L; l++) {
             for (uint32_t j = 0; j < 2 * nb; j++) hb.push_back(draw());   // permuted input rows, then table rows
@@ -503,8 +508,10 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         ctr += 1;
     }
     SHP_HIP(hipMemcpyAsync(pr->blinds, hb.data(), hb.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
+    pr->timers.begin(KID_GRAND_PRODUCT, st);
     hipLaunchKernelGGL(grand_product_kernel, dim3(1 + L), dim3(std::min<uint32_t>(1024, n)), 0, st, pr->num, pr->den, n, S, u,
                        bf, V(I_PZ), (size_t)n, pr->blinds);
+    pr->timers.end(st);
     hipLaunchKernelGGL(chacha_fr_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->key, ctr, n, pr->rand_poly);
     ctr += n;
     ctr += 1;
@@ -526,7 +533,9 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     pa.mult = y; pa.acc_in = nullptr;
     pa.prog = pk->gate_prog; pa.n_instr = (uint32_t)P.gate_prog.size(); pa.nslots = P.gate_slots;
     pa.out = pr->h;
+    pr->timers.begin(KID_PROG, st);
     launch_prog(st, pa, ne);
+    pr->timers.end(st);
     {
         PermQArgs q;
         q.p = pg;
@@ -727,6 +736,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     msm_run_ws(srs->msm_gl, pr->msm_ws, pr->wvals + n, n, n, 1, pts.data(), st);
     tr.write_point(pts[0].x, pts[0].y);
     SHP_HIP(hipGetLastError());
+    pr->proofs_done++;
     proof_out.swap(tr.proof);
     instances_out.swap(instances);
     (void)F;
@@ -776,6 +786,23 @@ int32_t shp_pk_commitments(const shp_pk* pk, void* h_fixed, size_t n_fixed, void
 
 int32_t shp_prover_create(shp_pk* pk, shp_prover** out) {
     return guarded([&] { prover_create_impl(pk, out); });
+}
+
+int32_t shp_prover_profile(shp_prover* p, int32_t enable) {
+    return guarded([&] {
+        SHP_REQUIRE(p, SHP_ERR_INVALID_ARG, "prover_profile: null prover");
+        p->timers.enabled = enable != 0;
+        p->timers.reset();
+    });
+}
+
+int32_t shp_prover_profile_read(shp_prover* p, uint32_t index, const char** name, uint64_t* launches, double* total_ms) {
+    return guarded([&] {
+        SHP_REQUIRE(p && index < KID_COUNT, SHP_ERR_INVALID_ARG, "prover_profile_read: bad argument");
+        if (name) *name = KERNEL_NAMES[index];
+        if (launches) *launches = p->timers.launches[index];
+        if (total_ms) *total_ms = p->timers.total_ms[index];
+    });
 }
 
 int32_t shp_prover_destroy(shp_prover* p) {
