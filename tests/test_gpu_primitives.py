@@ -151,7 +151,7 @@ def test_srs_synthetic_matches_oracle(shp, oracle, gpu_ctx):
     p.close()
 
 
-@pytest.mark.parametrize("n,window", [(1, 0), (5, 0), (100, 7), (2048, 0), (2048, 12), (8192, 0)])
+@pytest.mark.parametrize("n,window", [(1, 0), (5, 0), (100, 7), (2048, 0), (2048, 12), (8192, 0), (8192, 12)])
 def test_msm_matches_oracle(shp, oracle, gpu_ctx, n, window):
     osrs = oracle.srs_synthetic(13, 0xDEADBEEFCAFE1234567)
     bases = osrs.g[:n]

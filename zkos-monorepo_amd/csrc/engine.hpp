@@ -9,10 +9,11 @@ namespace shp {
 // `roofline` object needs the dominant kernel's average launch duration measured live).
 enum KernelId {
     KID_MSM_DIGITS = 0, KID_MSM_ACCUMULATE, KID_MSM_FIXUP, KID_MSM_REDUCE, KID_NTT, KID_PROG, KID_GRAND_PRODUCT,
-    KID_RANK_SORT, KID_BATCH_INVERT, KID_COUNT
+    KID_RANK_SORT, KID_BATCH_INVERT, KID_MSM_DIRECT, KID_MSM_DIRECT_FINAL, KID_COUNT
 };
 static const char* const KERNEL_NAMES[KID_COUNT] = {"msm_digits", "msm_accumulate", "msm_fixup", "msm_reduce", "ntt_pass",
-                                                    "prog_fold", "grand_product", "rank_sort", "batch_invert"};
+                                                    "prog_fold", "grand_product", "rank_sort", "batch_invert", "msm_direct",
+                                                    "msm_direct_final"};
 struct KernelTimers {
     bool enabled = false;
     struct Rec { int id; hipEvent_t a, b; };
@@ -73,7 +74,10 @@ struct shp_msm {
     shp_ctx* ctx = nullptr;
     size_t n = 0;
     uint32_t c = 0, W = 0, NB = 0;
-    shp::G1Affine* d_table = nullptr;
+    shp::G1Affine* d_table = nullptr;     // base rows 2^(c w) * P_i  [W][n]
+    bool direct = false;                  // direct-table mode: d_mult holds every digit multiple
+    shp::G1Affine* d_mult = nullptr;      // [W][n][NB]  d * 2^(c w) * P_i, d = 1..NB
+    shp::Fr bias;                         // signed-digit bias of the direct mode
     shp::MsmWorkspace ws;
     std::mutex mu;
 };

@@ -20,6 +20,9 @@
 //   * sum_b b * B_b: per-thread running sums over g buckets, an LDS suffix scan and a tree.
 //   * The handful of final XYZZ sums are normalised on the host (needed there anyway for the
 //     Keccak transcript).
+#include <algorithm>
+#include <stdlib.h>
+
 #include "engine.hpp"
 
 namespace shp {
@@ -272,6 +275,166 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_reduce_kernel(const G1X* buck
     if (t == 0) out[m] = sh[0][0];
 }
 
+// ================================================================== direct-table mode
+// For the prover's SRS (n <= 2^16 fixed bases, 288 GB of HBM) the plan stores EVERY digit multiple
+//   mult[(w * n + i) * NB + (d - 1)] = d * 2^(c w) * P_i,   d = 1 .. NB = 2^(c-1)
+// (n * W * NB * 64 B: 23.6 GB at n = 8192, c = 12), so an MSM has no buckets at all: it is the
+// plain sum of n * W gathered affine points.  No sort, no atomics, no bucket reduction; the
+// critical path is T mixed additions per lane plus a log-depth tree of XYZZ additions, and the
+// work is the minimum any window method can do (one mixed addition per non-zero digit).
+//
+// Signed digits without carry chains: with K = sum_{w < W-1} 2^(c(w+1)-1) added to the scalar once,
+// digit_w = ((s + K) >> cw & (2^c - 1)) - 2^(c-1) for w < W-1 and the top window is taken as is.
+
+// base rows -> all NB multiples, one wave per row, into XYZZ scratch + running zzz products
+__global__ __launch_bounds__(64) void msm_multiples_kernel(const G1Affine* __restrict__ rows, size_t row0, uint32_t n_rows,
+                                                           uint32_t NB, G1X* __restrict__ xyzz, Fq* __restrict__ pre,
+                                                           G1Affine* __restrict__ mult) {
+    const uint32_t r = blockIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t K = NB / 64;
+    const G1Affine B = rows[row0 + r];
+    G1Affine* out = mult + (row0 + r) * (size_t)NB;
+    if (B.is_inf()) {
+        G1Affine z; z.x = Fq::zero(); z.y = Fq::zero();
+        for (uint32_t t = 0; t < K; t++) out[(size_t)lane * K + t] = z;
+        return;
+    }
+    G1X* xs = xyzz + (size_t)r * NB + (size_t)lane * K;
+    Fq* ps = pre + (size_t)r * NB + (size_t)lane * K;
+    // KB = K * B (K is a power of two), S = lane * KB + B
+    G1X KB = G1X::from_affine(B);
+    for (uint32_t k = K; k > 1; k >>= 1) KB = g1_dbl(KB);
+    G1X S = G1X::inf();
+    for (int bit = 5; bit >= 0; bit--) {
+        S = g1_dbl(S);
+        if ((lane >> bit) & 1u) S = g1_add(S, KB);
+    }
+    S = g1_madd(S, B.x, B.y);
+    Fq acc = Fq::one();
+    for (uint32_t t = 0; t < K; t++) {
+        xs[t] = S;
+        ps[t] = acc;
+        acc = acc * S.zzz;               // d * B is never the identity for d < r
+        S = g1_madd(S, B.x, B.y);
+    }
+    // wave-wide Montgomery trick: one inversion for the 64 * K points of the row
+    Fq incl = acc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        Fq o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.l[i] = __shfl_up(incl.l[i], off);
+        if ((int)lane >= off) incl = incl * o;
+    }
+    Fq suf = acc;                          // inclusive suffix products
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        Fq o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.l[i] = __shfl_down(suf.l[i], off);
+        if ((int)lane + off < 64) suf = suf * o;
+    }
+    Fq total;
+#pragma unroll
+    for (int i = 0; i < 8; i++) total.l[i] = __shfl(incl.l[i], 63);
+    const Fq inv_total = Fq::inv(total);
+    Fq pre_excl, suf_excl;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        pre_excl.l[i] = __shfl_up(incl.l[i], 1);
+        suf_excl.l[i] = __shfl_down(suf.l[i], 1);
+    }
+    if (lane == 0) pre_excl = Fq::one();
+    if (lane == 63) suf_excl = Fq::one();
+    Fq inv = inv_total * pre_excl * suf_excl;     // 1 / (product of my K zzz)
+    for (int t = (int)K - 1; t >= 0; t--) {
+        const G1X P = xs[t];
+        const Fq zi = inv * ps[t];                // 1 / zzz_t
+        inv = inv * P.zzz;
+        const Fq zz_inv = Fq::sqr(zi * P.zz);     // (zz / zzz)^2 = 1 / zz
+        G1Affine a;
+        a.x = P.x * zz_inv;
+        a.y = P.y * zi;
+        out[(size_t)lane * K + t] = a;
+    }
+}
+
+struct DirectArgs {
+    const G1Affine* mult;
+    const Fr* scalars;
+    size_t n_scalars, stride, n_table;
+    uint32_t c, W, NB, T;
+    Fr bias;
+    G1X* partials;      // [batch][gridDim.y * gridDim.x]
+};
+
+__device__ __forceinline__ G1Affine load_affine(const G1Affine* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    G1Affine r;
+    r.x.l[0] = a.x; r.x.l[1] = a.y; r.x.l[2] = a.z; r.x.l[3] = a.w;
+    r.x.l[4] = b.x; r.x.l[5] = b.y; r.x.l[6] = b.z; r.x.l[7] = b.w;
+    r.y.l[0] = c.x; r.y.l[1] = c.y; r.y.l[2] = c.z; r.y.l[3] = c.w;
+    r.y.l[4] = d.x; r.y.l[5] = d.y; r.y.l[6] = d.z; r.y.l[7] = d.w;
+    return r;
+}
+
+// lane <-> scalar i, blockIdx.y <-> group of T windows, blockIdx.z <-> MSM of the batch
+__global__ __launch_bounds__(MSM_THREADS) void msm_direct_kernel(DirectArgs a) {
+    __shared__ G1X sh[MSM_THREADS / 64];
+    const size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x;
+    const uint32_t m = blockIdx.z;
+    const uint32_t w0 = blockIdx.y * a.T;
+    const uint32_t w1 = w0 + a.T < a.W ? w0 + a.T : a.W;
+    G1X acc = G1X::inf();
+    if (i < a.n_scalars) {
+        Fr raw = load_fr(a.scalars + (size_t)m * a.stride + i).to_raw();
+        if (!raw.is_zero()) {
+            uint64_t cy = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                cy += (uint64_t)raw.l[j] + a.bias.l[j];
+                raw.l[j] = (uint32_t)cy;
+                cy >>= 32;
+            }
+            const uint32_t half = a.NB;
+            for (uint32_t w = w0; w < w1; w++) {
+                uint32_t d = raw_bits(raw, w * a.c, a.c);
+                uint32_t neg = 0;
+                if (w + 1 < a.W) {
+                    neg = d < half;
+                    d = neg ? half - d : d - half;
+                }
+                if (d == 0) continue;
+                const G1Affine p = load_affine(a.mult + ((size_t)w * a.n_table + i) * a.NB + (d - 1));
+                if (p.is_inf()) continue;
+                const Fq y = neg ? Fq::neg(p.y) : p.y;
+                acc = g1_madd(acc, p.x, y);
+            }
+        }
+    }
+    for (int mask = 32; mask >= 1; mask >>= 1) acc = g1_add(acc, shfl_xor_point(acc, mask));
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        G1X s = g1_add(g1_add(sh[0], sh[1]), g1_add(sh[2], sh[3]));
+        a.partials[((size_t)m * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// one wave per MSM: sum of its P partials
+__global__ __launch_bounds__(64) void msm_direct_final_kernel(const G1X* partials, uint32_t P, G1X* out) {
+    const uint32_t m = blockIdx.x, lane = threadIdx.x;
+    const G1X* p = partials + (size_t)m * P;
+    G1X acc = G1X::inf();
+    for (uint32_t j = lane; j < P; j += 64) acc = g1_add(acc, p[j]);
+    for (int mask = 32; mask >= 1; mask >>= 1) acc = g1_add(acc, shfl_xor_point(acc, mask));
+    if (lane == 0) out[m] = acc;
+}
+
 }  // namespace shp
 
 using namespace shp;
@@ -285,15 +448,82 @@ static uint32_t pick_window(size_t n) {
     return (uint32_t)c;
 }
 
+// direct-table budget per plan (GiB); SHP_MSM_TABLE_GB=0 forces the bucket method
+static double direct_budget_gib() {
+    const char* e = getenv("SHP_MSM_TABLE_GB");
+    if (e && *e) return atof(e);
+    return 24.0;
+}
+
+static uint32_t direct_windows(uint32_t c) {
+    uint32_t W = (255 + c - 1) / c;
+    if (255 - (int)(c * (W - 1)) > (int)c - 1) W++;       // the unsigned top digit must be <= 2^(c-1)
+    return W;
+}
+
+// largest c in [8, 13] whose full multiples table fits the budget (0 = none: use buckets)
+static uint32_t pick_direct_window(size_t n) {
+    const double budget = direct_budget_gib() * 1073741824.0;
+    for (uint32_t c = 13; c >= 8; c--) {
+        double bytes = (double)n * direct_windows(c) * (double)(1u << (c - 1)) * sizeof(G1Affine);
+        if (bytes <= budget) return c;
+    }
+    return 0;
+}
+
+static void msm_build_direct(shp_ctx* ctx, shp_msm* m, const G1Affine* d_bases) {
+    const size_t n = m->n;
+    const uint32_t c = m->c, W = m->W, NB = m->NB;
+    hipStream_t st = ctx->stream;
+    SHP_HIP(hipMalloc(&m->d_table, (size_t)W * n * sizeof(G1Affine)));       // base rows 2^(cw) P_i
+    hipLaunchKernelGGL(msm_table_kernel, dim3(ceil_div(n, 128)), dim3(128), 0, st, d_bases, m->d_table, n, c, W);
+    SHP_HIP(hipGetLastError());
+    const size_t rows = (size_t)W * n;
+    SHP_HIP(hipMalloc(&m->d_mult, rows * NB * sizeof(G1Affine)));
+    // scratch for a batch of rows: XYZZ + running products, <= ~1.3 GB
+    size_t batch_rows = ((size_t)1 << 23) / NB;
+    if (batch_rows > rows) batch_rows = rows;
+    DevBuf xyzz, pre;
+    xyzz.reserve(batch_rows * NB * sizeof(G1X));
+    pre.reserve(batch_rows * NB * sizeof(Fq));
+    for (size_t r0 = 0; r0 < rows; r0 += batch_rows) {
+        uint32_t nr = (uint32_t)std::min(batch_rows, rows - r0);
+        hipLaunchKernelGGL(msm_multiples_kernel, dim3(nr), dim3(64), 0, st, m->d_table, r0, nr, NB, xyzz.as<G1X>(),
+                           pre.as<Fq>(), m->d_mult);
+    }
+    SHP_HIP(hipGetLastError());
+    SHP_HIP(hipStreamSynchronize(st));
+    xyzz.release();
+    pre.release();
+    // bias K = sum_{w < W-1} 2^(c(w+1)-1)
+    m->bias = Fr::zero();
+    for (uint32_t w = 0; w + 1 < W; w++) {
+        uint32_t bit = c * (w + 1) - 1;
+        m->bias.l[bit >> 5] |= 1u << (bit & 31);
+    }
+}
+
 static void msm_build(shp_ctx* ctx, const G1Affine* d_bases, size_t n, uint32_t window_bits, shp_msm** out) {
     SHP_REQUIRE(ctx && out && n > 0, SHP_ERR_INVALID_ARG, "msm_create: bad arguments");
+    std::unique_ptr<shp_msm> m(new shp_msm);
+    m->ctx = ctx;
+    m->n = n;
+    // window_bits == 0: direct multiples table when it fits the HBM budget, buckets otherwise;
+    // an explicit window_bits always selects the bucket method with that window
+    uint32_t cd = window_bits ? 0 : pick_direct_window(n);
+    if (cd) {
+        m->direct = true;
+        m->c = cd;
+        m->W = direct_windows(cd);
+        m->NB = 1u << (cd - 1);
+        msm_build_direct(ctx, m.get(), d_bases);
+        *out = m.release();
+        return;
+    }
     uint32_t c = window_bits ? window_bits : pick_window(n);
     SHP_REQUIRE(c >= 2 && c <= 20, SHP_ERR_INVALID_ARG, "msm_create: window_bits must be in [2,20]");
     uint32_t W = (255 + c - 1) / c;
     SHP_REQUIRE((uint64_t)n * W < (1ull << 31), SHP_ERR_INVALID_ARG, "msm_create: n * windows must be < 2^31");
-    std::unique_ptr<shp_msm> m(new shp_msm);
-    m->ctx = ctx;
-    m->n = n;
     m->c = c;
     m->W = W;
     m->NB = 1u << (c - 1);
@@ -304,11 +534,66 @@ static void msm_build(shp_ctx* ctx, const G1Affine* d_bases, size_t n, uint32_t 
     *out = m.release();
 }
 
+// host normalisation of `batch` XYZZ sums with one shared inversion (Montgomery's trick over ZZZ)
+static void normalise_batch(const std::vector<G1X>& in, uint32_t batch, G1Affine* h_out) {
+    std::vector<Fq> pre(batch);
+    Fq acc = Fq::one();
+    for (uint32_t b = 0; b < batch; b++) {
+        pre[b] = acc;
+        if (!in[b].is_inf()) acc = acc * in[b].zzz;
+    }
+    Fq inv = Fq::inv(acc);
+    for (uint32_t b = batch; b-- > 0;) {
+        const G1X& p = in[b];
+        if (p.is_inf()) { h_out[b].x = Fq::zero(); h_out[b].y = Fq::zero(); continue; }
+        Fq zi = inv * pre[b];
+        inv = inv * p.zzz;
+        Fq zz_inv = zi * zi * p.zz * p.zz;
+        h_out[b].x = p.x * zz_inv;
+        h_out[b].y = p.y * zi;
+    }
+}
+
+static void msm_run_direct(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n_scalars, size_t stride,
+                           uint32_t batch, G1Affine* h_out, hipStream_t st) {
+    const uint32_t W = m->W;
+    const uint32_t gx = ceil_div(n_scalars, MSM_THREADS);
+    // T windows per lane: short chains while the launch is small, 8 once the chip is full anyway
+    uint32_t T = 8;
+    while (T > 2 && (uint64_t)gx * ceil_div(W, T) * batch < 1024) T >>= 1;
+    const uint32_t gy = ceil_div(W, T);
+    const uint32_t P = gx * gy;
+    ws.pf.reserve((size_t)batch * P * sizeof(G1X));
+    ws.out.reserve((size_t)batch * sizeof(G1X));
+    DirectArgs a;
+    a.mult = m->d_mult; a.scalars = d_scalars; a.n_scalars = n_scalars; a.stride = stride; a.n_table = m->n;
+    a.c = m->c; a.W = W; a.NB = m->NB; a.T = T; a.bias = m->bias; a.partials = ws.pf.as<G1X>();
+    KernelTimers none, *tm = ws.timers ? ws.timers : &none;
+    tm->begin(KID_MSM_DIRECT, st);
+    hipLaunchKernelGGL(msm_direct_kernel, dim3(gx, gy, batch), dim3(MSM_THREADS), 0, st, a);
+    tm->end(st);
+    tm->begin(KID_MSM_DIRECT_FINAL, st);
+    hipLaunchKernelGGL(msm_direct_final_kernel, dim3(batch), dim3(64), 0, st, ws.pf.as<G1X>(), P, ws.out.as<G1X>());
+    tm->end(st);
+    SHP_HIP(hipGetLastError());
+    ws.h_out.resize(batch);
+    SHP_HIP(hipMemcpyAsync(ws.h_out.data(), ws.out.p, (size_t)batch * sizeof(G1X), hipMemcpyDeviceToHost, st));
+    SHP_HIP(hipStreamSynchronize(st));
+    tm->collect();
+    normalise_batch(ws.h_out, batch, h_out);
+    ws.last_adds = (uint64_t)batch * n_scalars * W;           // upper bound: one mixed add per non-zero digit
+    ws.last_bytes = (uint64_t)batch * n_scalars * 32 + (uint64_t)n_scalars * 64;
+}
+
 void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n_scalars, size_t stride,
                 uint32_t batch, G1Affine* h_out, hipStream_t st) {
     SHP_REQUIRE(m && d_scalars && h_out, SHP_ERR_INVALID_ARG, "msm: null argument");
     SHP_REQUIRE(n_scalars <= m->n, SHP_ERR_INVALID_ARG, "msm: more scalars than bases");
     if (batch == 0) return;
+    if (m->direct) {
+        msm_run_direct(m, ws, d_scalars, n_scalars, stride, batch, h_out, st);
+        return;
+    }
     const uint32_t NB = m->NB, W = m->W;
     const size_t entries_stride = n_scalars * W;
     const uint32_t T = entries_stride >= ((size_t)1 << 22) ? 64 : 16;
@@ -357,23 +642,7 @@ void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n
                              hipMemcpyDeviceToHost, st));
     SHP_HIP(hipStreamSynchronize(st));
     tm->collect();
-    // host normalisation with one shared inversion (Montgomery's trick over ZZZ)
-    std::vector<Fq> pre(batch);
-    Fq acc = Fq::one();
-    for (uint32_t b = 0; b < batch; b++) {
-        pre[b] = acc;
-        if (!ws.h_out[b].is_inf()) acc = acc * ws.h_out[b].zzz;
-    }
-    Fq inv = Fq::inv(acc);
-    for (uint32_t b = batch; b-- > 0;) {
-        const G1X& p = ws.h_out[b];
-        if (p.is_inf()) { h_out[b].x = Fq::zero(); h_out[b].y = Fq::zero(); continue; }
-        Fq zi = inv * pre[b];
-        inv = inv * p.zzz;
-        Fq zz_inv = zi * zi * p.zz * p.zz;
-        h_out[b].x = p.x * zz_inv;
-        h_out[b].y = p.y * zi;
-    }
+    normalise_batch(ws.h_out, batch, h_out);
     ws.last_adds = 0;
     for (uint32_t b = 0; b < batch; b++) ws.last_adds += ws.h_totals[b];
     ws.last_bytes = (uint64_t)batch * n_scalars * 32 + (uint64_t)n_scalars * 64;
@@ -413,6 +682,7 @@ int32_t shp_msm_destroy(shp_msm* m) {
     return guarded([&] {
         if (!m) return;
         if (m->d_table) (void)hipFree(m->d_table);
+        if (m->d_mult) (void)hipFree(m->d_mult);
         m->ws.release();
         delete m;
     });

@@ -75,7 +75,7 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     PlanData& P = pk->plan;
     P.parse(plan_bytes, len);
     SHP_REQUIRE(P.k == srs->k, SHP_ERR_INVALID_ARG, "keygen: plan k differs from the SRS k");
-    SHP_REQUIRE(P.n >= 64 && P.perm_cols.size() <= MAX_PERM_COLS && P.num_sets >= 1, SHP_ERR_INVALID_ARG,
+    SHP_REQUIRE(P.n >= 64 && P.k <= 16 && P.perm_cols.size() <= MAX_PERM_COLS && P.num_sets >= 1, SHP_ERR_INVALID_ARG,
                 "keygen: unsupported plan shape");
     keccak256(plan_bytes, len, P.plan_hash);
     const uint32_t n = P.n, k = P.k, ek = P.ext_k, ne = 1u << ek;
@@ -214,6 +214,10 @@ struct shp_prover {
     ShplonkArgs* shp_args = nullptr;
     Fr *blinds = nullptr, *ntt_tmp = nullptr;
     uint32_t* key = nullptr;
+    uint32_t* rank = nullptr;                                  // [2L][n] rank-sort scratch
+    Fr *sc_pre = nullptr, *sc_suf = nullptr;                   // [SC][n] block-local scans
+    Fr *sc_tot = nullptr;                                      // [6][SC][nb]: tot_a, tot_b, bpre_a, bsuf_b | [SC] inv
+    uint32_t sc_cnt = 0;
     std::vector<void*> owned;
     template <class T>
     T* dalloc(size_t count) {
@@ -267,6 +271,11 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->blinds = pr->dalloc<Fr>((size_t)(S + L + 2 * L) * (P.bf + 1) + 64);
     pr->ntt_tmp = pr->dalloc<Fr>((size_t)(NV + 1) * ne);
     pr->key = pr->dalloc<uint32_t>(8);
+    pr->rank = pr->dalloc<uint32_t>((size_t)2 * L * n);
+    pr->sc_cnt = std::max<uint32_t>(S + L, MAX_POINTS);
+    pr->sc_pre = pr->dalloc<Fr>((size_t)pr->sc_cnt * n);
+    pr->sc_suf = pr->dalloc<Fr>((size_t)pr->sc_cnt * n);
+    pr->sc_tot = pr->dalloc<Fr>((size_t)5 * pr->sc_cnt * SCAN_THREADS);
     pr->msm_ws.timers = &pr->timers;
     *out = pr.release();
 }
@@ -400,6 +409,24 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     auto V = [&](uint32_t idx) { return pr->vals + (size_t)idx * n; };
     auto PL = [&](uint32_t idx) { return pr->polys + (size_t)idx * n; };
     auto CS = [&](uint32_t idx) { return pr->cos + (size_t)idx * ne; };
+    // product scans over `cnt` vectors of n elements (prover_kernels.cuh "product scans")
+    const uint32_t sbs = std::min<uint32_t>(SCAN_THREADS, n), snb = n / sbs;
+    Fr* const sc_ta = pr->sc_tot;
+    Fr* const sc_tb = pr->sc_tot + (size_t)pr->sc_cnt * SCAN_THREADS;
+    Fr* const sc_bpre = pr->sc_tot + (size_t)2 * pr->sc_cnt * SCAN_THREADS;
+    Fr* const sc_bsuf = pr->sc_tot + (size_t)3 * pr->sc_cnt * SCAN_THREADS;
+    Fr* const sc_inv = pr->sc_tot + (size_t)4 * pr->sc_cnt * SCAN_THREADS;
+    auto product_scans = [&](const Fr* a, const Fr* b, uint32_t cnt) {
+        hipLaunchKernelGGL(scan_local_kernel, dim3(snb, cnt), dim3(sbs), 0, st, a, b, n, pr->sc_pre, pr->sc_suf, sc_ta, sc_tb);
+        hipLaunchKernelGGL(scan_totals_kernel, dim3(cnt), dim3(SCAN_THREADS), 0, st, sc_ta, sc_tb, snb, sc_bpre, sc_bsuf, sc_inv);
+    };
+    auto batch_invert = [&](const Fr* in, Fr* out, uint32_t cnt) {
+        pr->timers.begin(KID_BATCH_INVERT, st);
+        product_scans(in, in, cnt);
+        hipLaunchKernelGGL(batch_invert_apply_kernel, dim3(snb, cnt), dim3(sbs), 0, st, pr->sc_pre, pr->sc_suf, sc_bpre, sc_bsuf,
+                           sc_inv, n, out);
+        pr->timers.end(st);
+    };
 
     uint32_t key[8];
     memcpy(key, seed, 32);
@@ -466,8 +493,11 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
                                pr->sort_raw + (size_t)(2 * l + 1) * n, u);
         }
         pr->timers.begin(KID_RANK_SORT, st);
-        hipLaunchKernelGGL(rank_sort_kernel, dim3(ceil_div(u, 256), 2 * L), dim3(256), 0, st, pr->sort_raw, pr->sort_out, u,
-                           (size_t)n);
+        SHP_HIP(hipMemsetAsync(pr->rank, 0, (size_t)2 * L * n * 4, st));
+        hipLaunchKernelGGL(rank_count_kernel, dim3(ceil_div(u, 256), 2 * L, ceil_div(u, RANK_SLICE)), dim3(256), 0, st,
+                           pr->sort_raw, pr->rank, u, (size_t)n);
+        hipLaunchKernelGGL(rank_scatter_kernel, dim3(ceil_div(u, 256), 2 * L), dim3(256), 0, st, pr->sort_raw, pr->rank,
+                           pr->sort_out, u, (size_t)n);
         pr->timers.end(st);
         hb.clear();
         for (uint32_t l = 0; l < L; l++) {
@@ -509,8 +539,9 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     }
     SHP_HIP(hipMemcpyAsync(pr->blinds, hb.data(), hb.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
     pr->timers.begin(KID_GRAND_PRODUCT, st);
-    hipLaunchKernelGGL(grand_product_kernel, dim3(1 + L), dim3(std::min<uint32_t>(1024, n)), 0, st, pr->num, pr->den, n, S, u,
-                       bf, V(I_PZ), (size_t)n, pr->blinds);
+    product_scans(pr->num, pr->den, S + L);
+    hipLaunchKernelGGL(grand_product_apply_kernel, dim3(snb, S + L), dim3(sbs), 0, st, pr->sc_pre, pr->sc_suf, sc_bpre, sc_bsuf,
+                       sc_inv, n, S, u, bf, V(I_PZ), (size_t)n, pr->blinds);
     pr->timers.end(st);
     hipLaunchKernelGGL(chacha_fr_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->key, ctr, n, pr->rand_poly);
     ctr += n;
@@ -694,10 +725,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     hipLaunchKernelGGL(lincomb_kernel, dim3(ceil_div(n, 256), (uint32_t)sets.size()), dim3(256), 0, st, pr->lin, n, pr->fsets);
     hipLaunchKernelGGL(point_diff_kernel, dim3(ceil_div(n, 256), (uint32_t)points.size()), dim3(256), 0, st, pk->omegas,
                        pr->points, n, pr->pdiff);
-    {
-        uint32_t nt = std::min<uint32_t>(1024, n), per = n / nt;
-        hipLaunchKernelGGL(batch_invert_kernel, dim3((uint32_t)points.size()), dim3(nt), 0, st, pr->pdiff, pr->dinv, per);
-    }
+    batch_invert(pr->pdiff, pr->dinv, (uint32_t)points.size());
     hipLaunchKernelGGL(shplonk_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals);
     msm_run_ws(srs->msm_gl, pr->msm_ws, pr->wvals, n, n, 1, pts.data(), st);
     tr.write_point(pts[0].x, pts[0].y);
@@ -728,10 +756,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     SHP_HIP(hipMemcpyAsync(pr->shp_args, &sa, sizeof(sa), hipMemcpyHostToDevice, st));
     SHP_HIP(hipMemcpyAsync(pr->points, &mu, sizeof(Fr), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(point_diff_kernel, dim3(ceil_div(n, 256), 1), dim3(256), 0, st, pk->omegas, pr->points, n, pr->mdiff);
-    {
-        uint32_t nt = std::min<uint32_t>(1024, n), per = n / nt;
-        hipLaunchKernelGGL(batch_invert_kernel, dim3(1), dim3(nt), 0, st, pr->mdiff, pr->mdiff + n, per);
-    }
+    batch_invert(pr->mdiff, pr->mdiff + n, 1);
     hipLaunchKernelGGL(shplonk_wp_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals + n);
     msm_run_ws(srs->msm_gl, pr->msm_ws, pr->wvals + n, n, n, 1, pts.data(), st);
     tr.write_point(pts[0].x, pts[0].y);

@@ -175,53 +175,120 @@ __device__ __forceinline__ Fr block_scan_bwd_excl(Fr v, Fr* sh, uint32_t t, uint
     return r;
 }
 
-// z[0] = start, z[i+1] = z[i] * num[i] / den[i]; ONE field inversion per product (of the total
-// denominator): 1 / prod_{r<i} den_r = (prod_{r>=i} den_r) / prod_all.
-// block 0: the permutation sets, chained through z[usable]; block 1 + l: lookup l.
-// z_out[p] = zbase + p * zstride for product p in the order [perm sets..., lookups...].
-__global__ __launch_bounds__(1024) void grand_product_kernel(const Fr* num, const Fr* den, uint32_t n, uint32_t n_sets,
-                                                             uint32_t usable, uint32_t bf, Fr* zbase, size_t zstride,
-                                                             const Fr* blinds) {
-    __shared__ Fr sh[1024];
-    __shared__ Fr bc[2];
-    const uint32_t t = threadIdx.x, nt = blockDim.x;
-    const uint32_t per = n / nt;
-    const uint32_t first = blockIdx.x == 0 ? 0 : n_sets + blockIdx.x - 1;
-    const uint32_t count = blockIdx.x == 0 ? n_sets : 1;
-    Fr start = Fr::one();
-    for (uint32_t pi = 0; pi < count; pi++) {
-        const uint32_t p = first + pi;
-        const Fr* nu = num + (size_t)p * n;
-        const Fr* de = den + (size_t)p * n;
-        Fr* z = zbase + (size_t)p * zstride;
-        const uint32_t r0 = t * per;
-        Fr ln = Fr::one(), ldn = Fr::one();
-        for (uint32_t j = 0; j < per; j++) {
-            ln = ln * ld(nu + r0 + j);
-            ldn = ldn * ld(de + r0 + j);
-        }
-        Fr npre = block_scan_fwd_excl(ln, sh, t, nt);
-        Fr ssuf = block_scan_bwd_excl(ldn, sh, t, nt);
-        if (t == 0) bc[0] = Fr::inv(ldn * ssuf);
-        __syncthreads();
-        Fr inv_tot = bc[0];
-        Fr s = ssuf;
-        for (int j = (int)per - 1; j >= 0; j--) {
-            s = s * ld(de + r0 + j);
-            st(z + r0 + j, s);
-        }
-        Fr c = start * inv_tot * npre;
-        for (uint32_t j = 0; j < per; j++) {
-            Fr zi = c * ld(z + r0 + j);
-            st(z + r0 + j, zi);
-            if (r0 + j == usable) bc[1] = zi;
-            c = c * ld(nu + r0 + j);
-        }
-        __syncthreads();
-        start = bc[1];
-        if (t < bf) st(z + n - bf + t, ld(blinds + (size_t)p * bf + t));
-        __syncthreads();
+// ------------------------------------------------------------------ product scans over many workgroups
+// Prefix products of `a` and suffix products of `b` over `cnt` products of `n` elements each, in
+// three short launches instead of one long single-workgroup chain:
+//   scan_local   every min(256, n)-element block: exclusive prefix of a, inclusive suffix of b, block totals
+//   scan_totals  one workgroup per product: exclusive prefix / suffix of the block totals and the
+//                ONE inversion of the product of all b (binary Euclid, Fp::inv)
+//   apply        element-wise (grand_product_apply / batch_invert_apply)
+constexpr int SCAN_THREADS = 256;
+
+__device__ __forceinline__ Fr shfl_up_fr(const Fr& v, int d) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = __shfl_up(v.l[i], d);
+    return r;
+}
+__device__ __forceinline__ Fr shfl_down_fr(const Fr& v, int d) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = __shfl_down(v.l[i], d);
+    return r;
+}
+__device__ __forceinline__ Fr shfl_fr(const Fr& v, int src) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = __shfl(v.l[i], src);
+    return r;
+}
+
+// grid (n / bs, cnt), bs = blockDim.x = min(256, n).
+// pre_a[i] = prod_{block start <= r < i} a_r ; suf_b[i] = prod_{i <= r < block end} b_r
+__global__ __launch_bounds__(SCAN_THREADS) void scan_local_kernel(const Fr* a, const Fr* b, uint32_t n, Fr* pre_a, Fr* suf_b,
+                                                                  Fr* tot_a, Fr* tot_b) {
+    __shared__ Fr wa[SCAN_THREADS / 64], wb[SCAN_THREADS / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, bs = blockDim.x, nw = bs >> 6;
+    const size_t i = (size_t)blockIdx.y * n + (size_t)blockIdx.x * bs + t;
+    const Fr va = ld(a + i), vb = ld(b + i);
+    Fr ia = va, sb = vb;                   // inclusive prefix of a / inclusive suffix of b inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        Fr ua = shfl_up_fr(ia, off), db = shfl_down_fr(sb, off);
+        if ((int)lane >= off) ia = ia * ua;
+        if ((int)lane + off < 64) sb = sb * db;
     }
+    if (lane == 63) wa[wave] = ia;
+    if (lane == 0) wb[wave] = sb;
+    __syncthreads();
+    Fr ea = shfl_up_fr(ia, 1);             // exclusive prefix inside the wave
+    if (lane == 0) ea = Fr::one();
+    for (uint32_t w = 0; w < wave; w++) ea = ea * wa[w];
+    for (uint32_t w = wave + 1; w < nw; w++) sb = sb * wb[w];
+    st(pre_a + i, ea);
+    st(suf_b + i, sb);
+    if (t == 0) {
+        const uint32_t nb = n / bs;
+        Fr ta = wa[0], tb = wb[0];
+        for (uint32_t w = 1; w < nw; w++) { ta = ta * wa[w]; tb = tb * wb[w]; }
+        st(tot_a + (size_t)blockIdx.y * nb + blockIdx.x, ta);
+        st(tot_b + (size_t)blockIdx.y * nb + blockIdx.x, tb);
+    }
+}
+
+// grid (cnt), 256 threads, nb = n / 256 <= 256 block totals per product.
+// bpre_a[k] = prod_{j<k} tot_a[j]; bsuf_b[k] = prod_{j>k} tot_b[j]; inv_b = 1 / prod_j tot_b[j]
+__global__ __launch_bounds__(SCAN_THREADS) void scan_totals_kernel(const Fr* tot_a, const Fr* tot_b, uint32_t nb, Fr* bpre_a,
+                                                                   Fr* bsuf_b, Fr* inv_b) {
+    __shared__ Fr sh[SCAN_THREADS];
+    const uint32_t t = threadIdx.x, p = blockIdx.x;
+    const Fr va = t < nb ? ld(tot_a + (size_t)p * nb + t) : Fr::one();
+    const Fr vb = t < nb ? ld(tot_b + (size_t)p * nb + t) : Fr::one();
+    Fr ea = block_scan_fwd_excl(va, sh, t, SCAN_THREADS);
+    Fr eb = block_scan_bwd_excl(vb, sh, t, SCAN_THREADS);
+    if (t < nb) {
+        st(bpre_a + (size_t)p * nb + t, ea);
+        st(bsuf_b + (size_t)p * nb + t, eb);
+    }
+    if (t == 0) st(inv_b + p, Fr::inv(vb * eb));
+}
+
+// z[p][i] = c_p * prod_{r<i} num_r / prod_{r<i} den_r for i <= usable, blinding rows after it.
+// Products [0, n_sets) are the chained permutation sets (c_p = prod_{j<p} z_j[usable]); the rest
+// (lookups) start at 1.  grid (n / 256, cnt).
+__global__ __launch_bounds__(SCAN_THREADS) void grand_product_apply_kernel(const Fr* pre_num, const Fr* suf_den, const Fr* bpre,
+                                                                          const Fr* bsuf, const Fr* inv_den, uint32_t n,
+                                                                          uint32_t n_sets, uint32_t usable, uint32_t bf, Fr* zbase,
+                                                                          size_t zstride, const Fr* blinds) {
+    const uint32_t p = blockIdx.y, bs = blockDim.x, nb = n / bs;
+    const uint32_t i = blockIdx.x * bs + threadIdx.x;
+    Fr* z = zbase + (size_t)p * zstride;
+    if (i > usable) {
+        st(z + i, ld(blinds + (size_t)p * bf + (i - usable - 1)));
+        return;
+    }
+    auto zhat = [&](uint32_t q, uint32_t r) {
+        const size_t e = (size_t)q * n + r;
+        const size_t k = (size_t)q * nb + r / bs;
+        return ld(pre_num + e) * ld(bpre + k) * (ld(suf_den + e) * ld(bsuf + k)) * ld(inv_den + q);
+    };
+    Fr v = zhat(p, i);
+    if (p < n_sets)
+        for (uint32_t q = 0; q < p; q++) v = v * zhat(q, usable);
+    st(z + i, v);
+}
+
+// out[p][i] = 1 / in[p][i] from the scans of `in` against itself
+__global__ __launch_bounds__(SCAN_THREADS) void batch_invert_apply_kernel(const Fr* pre, const Fr* suf, const Fr* bpre, const Fr* bsuf,
+                                                                         const Fr* inv_tot, uint32_t n, Fr* out) {
+    const uint32_t p = blockIdx.y, bs = blockDim.x, nb = n / bs, t = threadIdx.x, lane = t & 63;
+    const size_t e = (size_t)p * n + (size_t)blockIdx.x * bs + t;
+    const size_t k = (size_t)p * nb + blockIdx.x;
+    // exclusive suffix inside the block = inclusive suffix of the next element (1 at the block end)
+    Fr sn = ld(suf + e);
+    Fr se = shfl_down_fr(sn, 1);
+    if (lane == 63) se = t + 1 < bs ? ld(suf + e + 1) : Fr::one();
+    st(out + e, ld(pre + e) * ld(bpre + k) * (se * ld(bsuf + k)) * ld(inv_tot + p));
 }
 
 // ------------------------------------------------------------------ lookup permutation
@@ -242,26 +309,36 @@ __global__ void to_raw_kernel(const Fr* in, Fr* out, uint32_t count) {
     if (i < count) st(out + i, ld(in + i).to_raw());
 }
 
-// sorted[rank(i)] = raw[i]; blockIdx.y selects the array (stride `stride`)
-__global__ __launch_bounds__(256) void rank_sort_kernel(const Fr* raw, Fr* sorted, uint32_t u, size_t stride) {
+// rank sort, spread over the chip: blockIdx.x = tile of 256 elements, blockIdx.y = array,
+// blockIdx.z = slice of the comparison range; partial ranks meet in `rank` (zeroed by the caller)
+constexpr uint32_t RANK_SLICE = 512;
+__global__ __launch_bounds__(256) void rank_count_kernel(const Fr* raw, uint32_t* rank, uint32_t u, size_t stride) {
     __shared__ Fr tile[256];
     const Fr* src = raw + (size_t)blockIdx.y * stride;
-    Fr* dst = sorted + (size_t)blockIdx.y * stride;
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    Fr mine = i < u ? ld(src + i) : Fr::zero();
-    uint32_t rank = 0;
-    for (uint32_t base = 0; base < u; base += 256) {
-        uint32_t j = base + threadIdx.x;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const Fr mine = i < u ? ld(src + i) : Fr::zero();
+    const uint32_t s0 = blockIdx.z * RANK_SLICE;
+    const uint32_t s1 = s0 + RANK_SLICE < u ? s0 + RANK_SLICE : u;
+    uint32_t r = 0;
+    for (uint32_t base = s0; base < s1; base += 256) {
+        const uint32_t j = base + threadIdx.x;
         __syncthreads();
-        if (j < u) tile[threadIdx.x] = ld(src + j);
+        if (j < s1) tile[threadIdx.x] = ld(src + j);
         __syncthreads();
-        uint32_t lim = u - base < 256 ? u - base : 256;
+        const uint32_t lim = s1 - base < 256 ? s1 - base : 256;
         for (uint32_t k = 0; k < lim; k++) {
             int c = raw_cmp(tile[k], mine);
-            rank += (c < 0 || (c == 0 && base + k < i)) ? 1u : 0u;
+            r += (c < 0 || (c == 0 && base + k < i)) ? 1u : 0u;
         }
     }
-    if (i < u) st(dst + rank, mine);
+    if (i < u && r) atomicAdd(rank + (size_t)blockIdx.y * stride + i, r);
+}
+// sorted[rank(i)] = raw[i]
+__global__ void rank_scatter_kernel(const Fr* raw, const uint32_t* rank, Fr* sorted, uint32_t u, size_t stride) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= u) return;
+    const size_t o = (size_t)blockIdx.y * stride;
+    st(sorted + o + rank[o + i], ld(raw + o + i));
 }
 
 __device__ __forceinline__ bool bsearch_raw(const Fr* arr, uint32_t count, const Fr& key) {
@@ -490,33 +567,6 @@ __global__ void point_diff_kernel(const Fr* omegas, const Fr* points, uint32_t n
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     st(d + (size_t)blockIdx.y * n + i, ld(omegas + i) - ld(points + blockIdx.y));
-}
-
-// out[i] = 1 / in[i] over blockDim.x * per contiguous elements per workgroup, with ONE Fermat
-// inversion per workgroup: inv(a_j) = inv(total) * (product of everything else)
-__global__ __launch_bounds__(1024) void batch_invert_kernel(const Fr* in, Fr* out, uint32_t per) {
-    __shared__ Fr sh[1024];
-    __shared__ Fr bc;
-    const uint32_t t = threadIdx.x, nt = blockDim.x;
-    const Fr* bi = in + ((size_t)blockIdx.x * nt + t) * per;
-    Fr* bo = out + ((size_t)blockIdx.x * nt + t) * per;
-    Fr prod = Fr::one();
-    for (uint32_t j = 0; j < per; j++) prod = prod * ld(bi + j);
-    Fr pre = block_scan_fwd_excl(prod, sh, t, nt);
-    Fr suf = block_scan_bwd_excl(prod, sh, t, nt);
-    if (t == 0) bc = Fr::inv(prod * suf);
-    __syncthreads();
-    const Fr outer = bc * pre * suf;             // 1 / (product of my chunk)
-    Fr run = Fr::one();
-    for (int j = (int)per - 1; j >= 0; j--) {
-        st(bo + j, run);                         // product of my elements to the right of j
-        run = run * ld(bi + j);
-    }
-    Fr left = outer;
-    for (uint32_t j = 0; j < per; j++) {
-        st(bo + j, left * ld(bo + j));
-        left = left * ld(bi + j);
-    }
 }
 
 struct ShplonkArgs {
