@@ -97,5 +97,7 @@ struct shp_srs {
 // `batch` MSMs over the plan's bases; synchronises `st` and normalises on the host
 void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const shp::Fr* d_scalars, size_t n_scalars, size_t stride,
                 uint32_t batch, shp::G1Affine* h_out, hipStream_t st);
+void msm_run_ws2(shp_msm* m, const shp::Fr* d_scalars, size_t stride, uint32_t batch, shp_msm* m2, const shp::Fr* d_scalars2,
+                 size_t stride2, uint32_t batch2, size_t n_scalars, shp::MsmWorkspace& ws, shp::G1Affine* h_out, hipStream_t st);
 void msm_run(shp_msm* m, const shp::Fr* d_scalars, size_t n_scalars, size_t stride, uint32_t batch,
              shp::G1Affine* h_out, hipStream_t st);

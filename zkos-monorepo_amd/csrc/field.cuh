@@ -60,6 +60,22 @@ struct FrParams {
     static constexpr uint32_t INV = 0xefffffffu;
 };
 
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 building blocks (measured, tools/ubench/instr_rate.hip): v_mad_u64_u32 issues at the
+// same 4 cycles per wave64 as a 32-bit add, so a 254-bit Montgomery product is priced by its
+// instruction COUNT.  hipcc's code for the portable CIOS loop is 128 mads + ~490 moves and 64-bit
+// adds; the product-scanning form below is 128 mads + 128 carry adds + ~50 moves.
+// (hi:lo) is a 96-bit column accumulator: lo += a * b, the carry out of bit 63 goes to hi.
+__device__ __forceinline__ void mac96(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "v"(b) : "vcc");
+}
+// same with a wave-uniform (compile-time constant) multiplier held in an SGPR
+__device__ __forceinline__ void mac96_k(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t k) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "s"(k) : "vcc");
+}
+#endif
+
 template <class PR>
 struct alignas(16) Fp {
     uint32_t l[8];
@@ -117,6 +133,27 @@ struct alignas(16) Fp {
 
     // r = a - p if a >= p (branch-free select)
     SHP_HD void reduce_once() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t t0, t1, t2, t3, t4, t5, t6, t7, keep;
+        asm("v_subrev_co_u32 %0, vcc, %17, %9\n\t"
+            "v_subbrev_co_u32 %1, vcc, %18, %10, vcc\n\t"
+            "v_subbrev_co_u32 %2, vcc, %19, %11, vcc\n\t"
+            "v_subbrev_co_u32 %3, vcc, %20, %12, vcc\n\t"
+            "v_subbrev_co_u32 %4, vcc, %21, %13, vcc\n\t"
+            "v_subbrev_co_u32 %5, vcc, %22, %14, vcc\n\t"
+            "v_subbrev_co_u32 %6, vcc, %23, %15, vcc\n\t"
+            "v_subbrev_co_u32 %7, vcc, %24, %16, vcc\n\t"
+            "v_cndmask_b32 %8, 0, -1, vcc"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(keep)
+            : "v"(l[0]), "v"(l[1]), "v"(l[2]), "v"(l[3]), "v"(l[4]), "v"(l[5]), "v"(l[6]), "v"(l[7]),
+              // the modulus sits in VGPRs: an SGPR source next to the VCC carry-in would be a second
+              // constant-bus read, which gfx9 encodings do not allow
+              "v"(PR::p(0)), "v"(PR::p(1)), "v"(PR::p(2)), "v"(PR::p(3)), "v"(PR::p(4)), "v"(PR::p(5)), "v"(PR::p(6)), "v"(PR::p(7))
+            : "vcc");
+        // keep = all ones where the subtraction borrowed (value < p)
+        l[0] = keep ? l[0] : t0; l[1] = keep ? l[1] : t1; l[2] = keep ? l[2] : t2; l[3] = keep ? l[3] : t3;
+        l[4] = keep ? l[4] : t4; l[5] = keep ? l[5] : t5; l[6] = keep ? l[6] : t6; l[7] = keep ? l[7] : t7;
+#else
         uint32_t t[8];
         uint64_t bw = 0;
 #pragma unroll
@@ -129,9 +166,26 @@ struct alignas(16) Fp {
 #pragma unroll
             for (int i = 0; i < 8; i++) l[i] = t[i];
         }
+#endif
     }
 
     static SHP_HD Fp add(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        Fp r = a;
+        asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+            "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+            "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
+            "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
+            "v_addc_co_u32 %4, vcc, %4, %12, vcc\n\t"
+            "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
+            "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
+            "v_addc_co_u32 %7, vcc, %7, %15, vcc"
+            : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7])
+            : "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+            : "vcc");
+        r.reduce_once();     // p < 2^254: no carry out of limb 7
+        return r;
+#else
         Fp r;
         uint64_t c = 0;
 #pragma unroll
@@ -142,8 +196,49 @@ struct alignas(16) Fp {
         }
         r.reduce_once();     // p < 2^254: no carry out of limb 7
         return r;
+#endif
     }
     static SHP_HD Fp sub(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        Fp r = a;
+        uint32_t mask, tmp;
+        asm("v_sub_co_u32 %0, vcc, %0, %9\n\t"
+            "v_subb_co_u32 %1, vcc, %1, %10, vcc\n\t"
+            "v_subb_co_u32 %2, vcc, %2, %11, vcc\n\t"
+            "v_subb_co_u32 %3, vcc, %3, %12, vcc\n\t"
+            "v_subb_co_u32 %4, vcc, %4, %13, vcc\n\t"
+            "v_subb_co_u32 %5, vcc, %5, %14, vcc\n\t"
+            "v_subb_co_u32 %6, vcc, %6, %15, vcc\n\t"
+            "v_subb_co_u32 %7, vcc, %7, %16, vcc\n\t"
+            "v_cndmask_b32 %8, 0, -1, vcc"
+            : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]),
+              "=&v"(mask)
+            : "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+            : "vcc");
+        // + p where the subtraction borrowed
+        asm("v_and_b32 %8, %10, %9\n\t"
+            "v_add_co_u32 %0, vcc, %0, %8\n\t"
+            "v_and_b32 %8, %11, %9\n\t"
+            "v_addc_co_u32 %1, vcc, %1, %8, vcc\n\t"
+            "v_and_b32 %8, %12, %9\n\t"
+            "v_addc_co_u32 %2, vcc, %2, %8, vcc\n\t"
+            "v_and_b32 %8, %13, %9\n\t"
+            "v_addc_co_u32 %3, vcc, %3, %8, vcc\n\t"
+            "v_and_b32 %8, %14, %9\n\t"
+            "v_addc_co_u32 %4, vcc, %4, %8, vcc\n\t"
+            "v_and_b32 %8, %15, %9\n\t"
+            "v_addc_co_u32 %5, vcc, %5, %8, vcc\n\t"
+            "v_and_b32 %8, %16, %9\n\t"
+            "v_addc_co_u32 %6, vcc, %6, %8, vcc\n\t"
+            "v_and_b32 %8, %17, %9\n\t"
+            "v_addc_co_u32 %7, vcc, %7, %8, vcc"
+            : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]),
+              "=&v"(tmp)
+            : "v"(mask), "s"(PR::p(0)), "s"(PR::p(1)), "s"(PR::p(2)), "s"(PR::p(3)), "s"(PR::p(4)), "s"(PR::p(5)), "s"(PR::p(6)),
+              "s"(PR::p(7))
+            : "vcc");
+        return r;
+#else
         Fp r;
         uint64_t bw = 0;
 #pragma unroll
@@ -161,6 +256,7 @@ struct alignas(16) Fp {
             c >>= 32;
         }
         return r;
+#endif
     }
     static SHP_HD Fp neg(const Fp& a) {
         if (a.is_zero()) return a;
@@ -182,37 +278,11 @@ struct alignas(16) Fp {
 #if !defined(__HIP_DEVICE_COMPILE__)
         return mul_host64(a, b);
 #else
-        uint32_t t[8];
-        uint32_t t8 = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) t[i] = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint64_t c = 0;
-            const uint32_t bi = b.l[i];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                c += (uint64_t)a.l[j] * bi + t[j];
-                t[j] = (uint32_t)c;
-                c >>= 32;
-            }
-            uint64_t top = (uint64_t)t8 + c;             // < 2^33
-            const uint32_t m = t[0] * PR::INV;
-            c = ((uint64_t)m * PR::p(0) + t[0]) >> 32;
-#pragma unroll
-            for (int j = 1; j < 8; j++) {
-                c += (uint64_t)m * PR::p(j) + t[j];
-                t[j - 1] = (uint32_t)c;
-                c >>= 32;
-            }
-            top += c;
-            t[7] = (uint32_t)top;
-            t8 = (uint32_t)(top >> 32);
-        }
-        Fp r;
-#pragma unroll
-        for (int i = 0; i < 8; i++) r.l[i] = t[i];
-        // t8 is 0 for p < 2^254 with reduced inputs; with one raw 256-bit input the value is
+        // finely integrated product scanning (FIPS): column k sums a_i b_{k-i} and m_i p_{k-i} in one
+        // 96-bit accumulator; m_k clears the column's low word; the upper columns are the result.
+        // One asm statement per column (tools/gen_field_mul.py).
+#include "field_mul_gfx950.inc"
+        // the 2^256 word is 0 for p < 2^254 with reduced inputs; with one raw 256-bit input the value is
         // still < 2p, and 2p < 2^256, so a single conditional subtraction is enough.
         r.reduce_once();
         return r;

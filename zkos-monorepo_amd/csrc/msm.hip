@@ -362,9 +362,13 @@ __global__ __launch_bounds__(64) void msm_multiples_kernel(const G1Affine* __res
 }
 
 struct DirectArgs {
-    const G1Affine* mult;
-    const Fr* scalars;
-    size_t n_scalars, stride, n_table;
+    // up to two segments of the batch, each over its own multiples table (same n, c, W):
+    // MSM m < split uses segment 0, the rest segment 1
+    const G1Affine* mult[2];
+    const Fr* scalars[2];
+    size_t stride[2];
+    uint32_t split;
+    size_t n_scalars, n_table;
     uint32_t c, W, NB, T;
     Fr bias;
     G1X* partials;      // [batch][gridDim.y * gridDim.x]
@@ -381,16 +385,48 @@ __device__ __forceinline__ G1Affine load_affine(const G1Affine* p) {
     return r;
 }
 
+// Sum of one XYZZ point per thread over a 256-thread workgroup; the result is valid in thread 0.
+// The tree runs through LDS in [dword][thread] order (conflict free) so that each level is
+// executed by as few WAVES as hold its live lanes (2, then 1) -- a __shfl butterfly would make all
+// four waves execute all eight levels: 26 wave-level additions instead of 9.
+__device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [32][256] */) {
+    const uint32_t t = threadIdx.x;
+    auto put = [&](const G1X& p) {
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(&p);
+#pragma unroll
+        for (int i = 0; i < 32; i++) sh[i * MSM_THREADS + t] = s[i];
+    };
+    auto get = [&](uint32_t from) {
+        G1X p;
+        uint32_t* d = reinterpret_cast<uint32_t*>(&p);
+#pragma unroll
+        for (int i = 0; i < 32; i++) d[i] = sh[i * MSM_THREADS + from];
+        return p;
+    };
+    if (t >= 128) put(acc);
+    __syncthreads();
+    if (t < 128) acc = g1_add(acc, get(t + 128));
+    if (t >= 64 && t < 128) put(acc);              // slots [64,128): nobody reads them before the barrier
+    __syncthreads();
+    if (t < 64) {
+        acc = g1_add(acc, get(t + 64));
+        for (int mask = 32; mask >= 1; mask >>= 1) acc = g1_add(acc, shfl_xor_point(acc, mask));
+    }
+    return acc;
+}
+
 // lane <-> scalar i, blockIdx.y <-> group of T windows, blockIdx.z <-> MSM of the batch
-__global__ __launch_bounds__(MSM_THREADS) void msm_direct_kernel(DirectArgs a) {
-    __shared__ G1X sh[MSM_THREADS / 64];
+__global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a) {
+    __shared__ uint32_t sh[32 * MSM_THREADS];
     const size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x;
-    const uint32_t m = blockIdx.z;
+    const uint32_t seg = blockIdx.z >= a.split ? 1u : 0u;
+    const uint32_t m = blockIdx.z - (seg ? a.split : 0u);
+    const G1Affine* __restrict__ mult = a.mult[seg];
     const uint32_t w0 = blockIdx.y * a.T;
     const uint32_t w1 = w0 + a.T < a.W ? w0 + a.T : a.W;
     G1X acc = G1X::inf();
     if (i < a.n_scalars) {
-        Fr raw = load_fr(a.scalars + (size_t)m * a.stride + i).to_raw();
+        Fr raw = load_fr(a.scalars[seg] + (size_t)m * a.stride[seg] + i).to_raw();
         if (!raw.is_zero()) {
             uint64_t cy = 0;
 #pragma unroll
@@ -408,31 +444,26 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_direct_kernel(DirectArgs a) {
                     d = neg ? half - d : d - half;
                 }
                 if (d == 0) continue;
-                const G1Affine p = load_affine(a.mult + ((size_t)w * a.n_table + i) * a.NB + (d - 1));
+                const G1Affine p = load_affine(mult + ((size_t)w * a.n_table + i) * a.NB + (d - 1));
                 if (p.is_inf()) continue;
                 const Fq y = neg ? Fq::neg(p.y) : p.y;
                 acc = g1_madd(acc, p.x, y);
             }
         }
     }
-    for (int mask = 32; mask >= 1; mask >>= 1) acc = g1_add(acc, shfl_xor_point(acc, mask));
-    const uint32_t wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) sh[wave] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        G1X s = g1_add(g1_add(sh[0], sh[1]), g1_add(sh[2], sh[3]));
-        a.partials[((size_t)m * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
-    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) a.partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = acc;
 }
 
-// one wave per MSM: sum of its P partials
-__global__ __launch_bounds__(64) void msm_direct_final_kernel(const G1X* partials, uint32_t P, G1X* out) {
-    const uint32_t m = blockIdx.x, lane = threadIdx.x;
+// one workgroup per MSM: sum of its P partials
+__global__ __launch_bounds__(MSM_THREADS) void msm_direct_final_kernel(const G1X* partials, uint32_t P, G1X* out) {
+    __shared__ uint32_t sh[32 * MSM_THREADS];
+    const uint32_t m = blockIdx.x;
     const G1X* p = partials + (size_t)m * P;
     G1X acc = G1X::inf();
-    for (uint32_t j = lane; j < P; j += 64) acc = g1_add(acc, p[j]);
-    for (int mask = 32; mask >= 1; mask >>= 1) acc = g1_add(acc, shfl_xor_point(acc, mask));
-    if (lane == 0) out[m] = acc;
+    for (uint32_t j = threadIdx.x; j < P; j += MSM_THREADS) acc = g1_add(acc, p[j]);
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) out[m] = acc;
 }
 
 }  // namespace shp
@@ -555,34 +586,57 @@ static void normalise_batch(const std::vector<G1X>& in, uint32_t batch, G1Affine
 }
 
 static void msm_run_direct(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n_scalars, size_t stride,
-                           uint32_t batch, G1Affine* h_out, hipStream_t st) {
-    const uint32_t W = m->W;
+                           uint32_t batch, G1Affine* h_out, hipStream_t st, shp_msm* m2 = nullptr,
+                           const Fr* d_scalars2 = nullptr, size_t stride2 = 0, uint32_t batch2 = 0) {
+    const uint32_t W = m->W, total = batch + batch2;
+    if (batch2) SHP_REQUIRE(m2 && m2->direct && m2->n == m->n && m2->c == m->c && m2->W == W, SHP_ERR_INVALID_ARG,
+                            "msm: the two segments need plans of the same shape");
     const uint32_t gx = ceil_div(n_scalars, MSM_THREADS);
-    // T windows per lane: short chains while the launch is small, 8 once the chip is full anyway
-    uint32_t T = 8;
-    while (T > 2 && (uint64_t)gx * ceil_div(W, T) * batch < 1024) T >>= 1;
+    // T windows per lane: all of them when the launch fills the chip anyway (least tree overhead),
+    // shorter chains for small launches (latency)
+    const uint32_t cand[5] = {W, (W + 1) / 2, 8, 4, 2};
+    uint32_t T = 2;
+    for (uint32_t t : cand)
+        if (t <= W && (uint64_t)gx * (MSM_THREADS / 64) * ceil_div(W, t) * total >= 1024) { T = t; break; }
     const uint32_t gy = ceil_div(W, T);
     const uint32_t P = gx * gy;
-    ws.pf.reserve((size_t)batch * P * sizeof(G1X));
-    ws.out.reserve((size_t)batch * sizeof(G1X));
+    ws.pf.reserve((size_t)total * P * sizeof(G1X));
+    ws.out.reserve((size_t)total * sizeof(G1X));
     DirectArgs a;
-    a.mult = m->d_mult; a.scalars = d_scalars; a.n_scalars = n_scalars; a.stride = stride; a.n_table = m->n;
+    a.mult[0] = m->d_mult; a.scalars[0] = d_scalars; a.stride[0] = stride;
+    a.mult[1] = m2 ? m2->d_mult : m->d_mult; a.scalars[1] = d_scalars2; a.stride[1] = stride2;
+    a.split = batch;
+    a.n_scalars = n_scalars; a.n_table = m->n;
     a.c = m->c; a.W = W; a.NB = m->NB; a.T = T; a.bias = m->bias; a.partials = ws.pf.as<G1X>();
     KernelTimers none, *tm = ws.timers ? ws.timers : &none;
     tm->begin(KID_MSM_DIRECT, st);
-    hipLaunchKernelGGL(msm_direct_kernel, dim3(gx, gy, batch), dim3(MSM_THREADS), 0, st, a);
+    hipLaunchKernelGGL(msm_direct_kernel, dim3(gx, gy, total), dim3(MSM_THREADS), 0, st, a);
     tm->end(st);
     tm->begin(KID_MSM_DIRECT_FINAL, st);
-    hipLaunchKernelGGL(msm_direct_final_kernel, dim3(batch), dim3(64), 0, st, ws.pf.as<G1X>(), P, ws.out.as<G1X>());
+    hipLaunchKernelGGL(msm_direct_final_kernel, dim3(total), dim3(MSM_THREADS), 0, st, ws.pf.as<G1X>(), P, ws.out.as<G1X>());
     tm->end(st);
     SHP_HIP(hipGetLastError());
-    ws.h_out.resize(batch);
-    SHP_HIP(hipMemcpyAsync(ws.h_out.data(), ws.out.p, (size_t)batch * sizeof(G1X), hipMemcpyDeviceToHost, st));
+    ws.h_out.resize(total);
+    SHP_HIP(hipMemcpyAsync(ws.h_out.data(), ws.out.p, (size_t)total * sizeof(G1X), hipMemcpyDeviceToHost, st));
     SHP_HIP(hipStreamSynchronize(st));
     tm->collect();
-    normalise_batch(ws.h_out, batch, h_out);
-    ws.last_adds = (uint64_t)batch * n_scalars * W;           // upper bound: one mixed add per non-zero digit
-    ws.last_bytes = (uint64_t)batch * n_scalars * 32 + (uint64_t)n_scalars * 64;
+    normalise_batch(ws.h_out, total, h_out);
+    ws.last_adds = (uint64_t)total * n_scalars * W;           // upper bound: one mixed add per non-zero digit
+    ws.last_bytes = (uint64_t)total * n_scalars * 32 + (uint64_t)n_scalars * 64;
+}
+
+// `batch` MSMs over m and `batch2` over m2 (both direct-table plans of one shape) in ONE launch;
+// h_out receives batch + batch2 points
+void msm_run_ws2(shp_msm* m, const Fr* d_scalars, size_t stride, uint32_t batch, shp_msm* m2, const Fr* d_scalars2,
+                 size_t stride2, uint32_t batch2, size_t n_scalars, shp::MsmWorkspace& ws, G1Affine* h_out, hipStream_t st) {
+    SHP_REQUIRE(m && m2 && d_scalars && d_scalars2 && h_out && batch && batch2, SHP_ERR_INVALID_ARG, "msm2: bad argument");
+    SHP_REQUIRE(n_scalars <= m->n, SHP_ERR_INVALID_ARG, "msm: more scalars than bases");
+    if (m->direct && m2->direct) {
+        msm_run_direct(m, ws, d_scalars, n_scalars, stride, batch, h_out, st, m2, d_scalars2, stride2, batch2);
+        return;
+    }
+    msm_run_ws(m, ws, d_scalars, n_scalars, stride, batch, h_out, st);
+    msm_run_ws(m2, ws, d_scalars2, n_scalars, stride2, batch2, h_out + batch, st);
 }
 
 void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n_scalars, size_t stride,

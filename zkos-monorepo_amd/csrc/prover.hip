@@ -453,9 +453,13 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     SHP_HIP(hipMemcpyAsync(pr->key, key, 32, hipMemcpyHostToDevice, st));
     Transcript tr(pk->vk_digest);
     for (auto& v : instances) tr.common_scalar(v);
-    // ---- P2: advice commitments
-    std::vector<G1Affine> pts(std::max<uint32_t>({A, 2 * L, S + L + 1, P.degree}));
-    msm_run_ws(srs->msm_gl, pr->msm_ws, V(0), n, n, A, pts.data(), st);
+    // ---- P2: advice commitments.  The random polynomial of P7 depends on no challenge: its
+    // coefficients (blinding stream position known up front) and its commitment ride in the same launch.
+    const uint64_t ctr_rand = (uint64_t)A * nb + A + (uint64_t)L * (2 * nb + 2) + (uint64_t)(S + L) * (bf + 1);
+    hipLaunchKernelGGL(chacha_fr_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->key, ctr_rand, n, pr->rand_poly);
+    std::vector<G1Affine> pts(std::max<uint32_t>({A + 1, 2 * L, S + L + 1, P.degree}));
+    msm_run_ws2(srs->msm_gl, V(0), n, A, srs->msm_g, pr->rand_poly, n, 1, n, pr->msm_ws, pts.data(), st);
+    const G1Affine rand_comm = pts[A];
     for (uint32_t c = 0; c < A; c++) tr.write_point(pts[c].x, pts[c].y);
     const Fr theta = tr.squeeze();
 
@@ -543,13 +547,12 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     hipLaunchKernelGGL(grand_product_apply_kernel, dim3(snb, S + L), dim3(sbs), 0, st, pr->sc_pre, pr->sc_suf, sc_bpre, sc_bsuf,
                        sc_inv, n, S, u, bf, V(I_PZ), (size_t)n, pr->blinds);
     pr->timers.end(st);
-    hipLaunchKernelGGL(chacha_fr_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->key, ctr, n, pr->rand_poly);
+    SHP_REQUIRE(ctr == ctr_rand, SHP_ERR_INTERNAL, "prove: blinding stream position of the random polynomial");
     ctr += n;
     ctr += 1;
     msm_run_ws(srs->msm_gl, pr->msm_ws, V(I_PZ), n, n, S + L, pts.data(), st);
     for (uint32_t i = 0; i < S + L; i++) tr.write_point(pts[i].x, pts[i].y);
-    msm_run_ws(srs->msm_g, pr->msm_ws, pr->rand_poly, n, n, 1, pts.data(), st);
-    tr.write_point(pts[0].x, pts[0].y);
+    tr.write_point(rand_comm.x, rand_comm.y);
     // ---- P8
     const Fr y = tr.squeeze();
     // ---- P9: coefficient forms and cosets of everything committed so far (+ instance column)

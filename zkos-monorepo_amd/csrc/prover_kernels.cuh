@@ -440,7 +440,7 @@ struct PermQArgs {
     Fr* h;
 };
 
-__global__ void perm_quotient_kernel(PermQArgs a) {
+__global__ __launch_bounds__(256, 2) void perm_quotient_kernel(PermQArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t ne = (size_t)a.mask + 1;
     Fr h = ld(a.h + i);
