@@ -8,8 +8,8 @@
 Workload (BASELINE.json configs[1]): the 2^13 withdraw-shaped circuit plan, synthetic SRS
 (tau known, k = 13), `random_correct_example` witnesses; SRS, proving key and window tables are
 resident in HBM before the timed region.  One STEP = every proving lane of the GPU (L host threads,
-each with its own HIP stream and HBM workspace) produces one complete proof: L independent proofs
-per step per GPU.  Proofs are independent, so N GPUs shard them with no collective on the data
+each with its own HIP stream and HBM workspace) produces --proofs-per-lane complete proofs back to
+back: L x B independent proofs per step per GPU.  Proofs are independent, so N GPUs shard them with no collective on the data
 path (weak scaling: per-GPU work is fixed); torch.distributed (RCCL) is used only for the
 barrier and the max-over-ranks of the elapsed time.
 
@@ -31,6 +31,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# proving lanes are HIP streams: give them hardware queues of their own (see zkos-monorepo_amd/binding.py);
+# must be in the environment before the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 TAU = 0x2B6F1C0A94D3E5F7081A2B3C4D5E6F70_13
@@ -69,7 +72,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--lanes", type=int, default=8, help="concurrent proving lanes (streams) per GPU")
+    ap.add_argument("--lanes", type=int, default=16, help="concurrent proving lanes (streams) per GPU")
+    ap.add_argument("--proofs-per-lane", type=int, default=4, help="proofs each lane produces back to back in one step")
     ap.add_argument("--latency-proofs", type=int, default=20)
     ap.add_argument("--cpu-proofs", type=int, default=3, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)   # gloo path test, no GPU
@@ -133,11 +137,12 @@ def main():
             if stop[0]:
                 return
             try:
-                seed = ((rank << 40) | (i << 32) | j).to_bytes(32, "little")
-                pr.prove_bytes(wits[(i + j) % len(wits)], seed)
+                for _ in range(a.proofs_per_lane):
+                    seed = ((rank << 40) | (i << 32) | j).to_bytes(32, "little")
+                    pr.prove_bytes(wits[(i + j) % len(wits)], seed)
+                    j += 1
             except Exception as e:      # noqa: BLE001
                 errors.append(e)
-            j += 1
             done.release()
 
     threads = [threading.Thread(target=lane, args=(i,), daemon=True) for i in range(a.lanes)]
@@ -149,7 +154,7 @@ def main():
             g.release()
         for _ in provers:
             done.acquire()
-        counter[0] += len(provers)
+        counter[0] += len(provers) * a.proofs_per_lane
         if errors:
             raise errors[0]
 
@@ -171,7 +176,7 @@ def main():
             prof[name] = (c0 + cnt, m0 + ms)
         pr.profile(False)
     elapsed = aggregate(elapsed, world, dist)
-    proofs_per_step = a.lanes
+    proofs_per_step = a.lanes * a.proofs_per_lane
     total_proofs = n_gpus * a.steps * proofs_per_step
 
     # single-lane latency (p50), outside the timed region
@@ -191,13 +196,13 @@ def main():
         # dominant kernel family of the timed region, by summed HIP-event time
         dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (0, 0.0))
         name, (cnt, ms) = dom
-        launches_per_proof = cnt / max(1, a.steps * a.lanes)
+        launches_per_proof = cnt / max(1, a.steps * proofs_per_step)
         # algorithmic bytes of one MSM launch: 96 B per point: 32 B scalar + 64 B base.
-        # The prover issues 25 MSMs of n points per proof in 7 batched launches: the
-        # average launch moves 25/7 scalar vectors + one base table.
-        msm_launch_bytes = (25.0 / 7.0) * 32 * n + 64 * n
+        # The prover issues 25 MSMs of n points per proof in 6 batched launches: the
+        # average launch moves 25/6 scalar vectors + one base table.
+        msm_launch_bytes = (25.0 / 6.0) * 32 * n + 64 * n
         alg_bytes = {"msm_digits": msm_launch_bytes / 2, "msm_accumulate": msm_launch_bytes, "msm_fixup": msm_launch_bytes,
-                     "msm_reduce": msm_launch_bytes, "prog_fold": 65536 * 32 * 47, "grand_product": 3 * 3 * n * 32,
+                     "msm_reduce": msm_launch_bytes, "msm_direct": msm_launch_bytes, "msm_direct_final": msm_launch_bytes, "prog_fold": 65536 * 32 * 47, "grand_product": 3 * 3 * n * 32,
                      "rank_sort": 2 * 2 * n * 32, "ntt_pass": 64 * 65536}.get(name, msm_launch_bytes)
         avg_s = (ms / cnt) * 1e-3 if cnt else float("inf")
         achieved = alg_bytes / avg_s / 1e9 if cnt else 0.0
@@ -223,7 +228,7 @@ def main():
                          "avg_launch_us": 1e6 * avg_s if cnt else None, "launches_per_proof": launches_per_proof,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "k=13 kernels are integer-ALU/latency bound, not HBM bound (DESIGN.md Rooflines)"},
-            "kernel_ms_per_proof": {k_: v[1] / max(1, a.steps * a.lanes) for k_, v in sorted(prof.items())},
+            "kernel_ms_per_proof": {k_: v[1] / max(1, a.steps * proofs_per_step) for k_, v in sorted(prof.items())},
         }
         if world == 1 and a.cpu_proofs > 0:
             out["cpu_baseline"] = cpu_baseline(plan, lay, a.cpu_proofs)

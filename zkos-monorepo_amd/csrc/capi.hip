@@ -2,6 +2,7 @@
 // management, the field front door, the NTT entry points and the SRS ("Params") object.
 #include <string.h>
 
+#include <stdlib.h>
 #include "engine.hpp"
 
 namespace shp {
@@ -138,6 +139,15 @@ static void read_points(const uint8_t* p, size_t n, std::vector<G1Affine>& out) 
         SHP_REQUIRE(on_curve(out[i]), SHP_ERR_FORMAT, "srs: G1 point not on curve");
     }
 }
+
+// Proving lanes are HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default
+// 4) and streams sharing a queue serialise.  Runs at load time, i.e. before this library's first HIP
+// call; it has no effect if the host process initialised HIP earlier with another value.
+namespace {
+struct HwQueueDefault {
+    HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+} g_hw_queue_default;
+}  // namespace
 
 extern "C" {
 

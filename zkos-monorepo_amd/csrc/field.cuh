@@ -425,6 +425,9 @@ struct alignas(16) Fp {
     // then one product by R^3 to return to Montgomery form: (aR)^-1 * R^3 / R = a^-1 R.
     static SHP_HD Fp inv(const Fp& a) {
         if (a.is_zero()) return a;
+#if defined(__HIP_DEVICE_COMPILE__)
+        return inv_kaliski(a);
+#else
         Fp u = a, v = modulus();
         Fp x1 = zero(), x2 = zero();
         x1.l[0] = 1;
@@ -448,7 +451,95 @@ struct alignas(16) Fp {
 #pragma unroll
         for (int i = 0; i < 8; i++) r3.l[i] = PR::r3(i);
         return mul(u.raw_is_one() ? x1 : x2, r3);
+#endif
     }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    // raw 256-bit carry chains (no reduction)
+    static __device__ __forceinline__ void raw_add_to(Fp& r, const Fp& b) {
+        asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+            "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+            "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
+            "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
+            "v_addc_co_u32 %4, vcc, %4, %12, vcc\n\t"
+            "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
+            "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
+            "v_addc_co_u32 %7, vcc, %7, %15, vcc"
+            : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7])
+            : "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+            : "vcc");
+    }
+    // d = a - b (mod 2^256); returns all ones when it borrowed (a < b)
+    static __device__ __forceinline__ uint32_t raw_sub_borrow(Fp& d, const Fp& a, const Fp& b) {
+        d = a;
+        uint32_t mask;
+        asm("v_sub_co_u32 %0, vcc, %0, %9\n\t"
+            "v_subb_co_u32 %1, vcc, %1, %10, vcc\n\t"
+            "v_subb_co_u32 %2, vcc, %2, %11, vcc\n\t"
+            "v_subb_co_u32 %3, vcc, %3, %12, vcc\n\t"
+            "v_subb_co_u32 %4, vcc, %4, %13, vcc\n\t"
+            "v_subb_co_u32 %5, vcc, %5, %14, vcc\n\t"
+            "v_subb_co_u32 %6, vcc, %6, %15, vcc\n\t"
+            "v_subb_co_u32 %7, vcc, %7, %16, vcc\n\t"
+            "v_cndmask_b32 %8, 0, -1, vcc"
+            : "+v"(d.l[0]), "+v"(d.l[1]), "+v"(d.l[2]), "+v"(d.l[3]), "+v"(d.l[4]), "+v"(d.l[5]), "+v"(d.l[6]), "+v"(d.l[7]),
+              "=&v"(mask)
+            : "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+            : "vcc");
+        return mask;
+    }
+    __device__ __forceinline__ void raw_shl1() {
+#pragma unroll
+        for (int i = 7; i > 0; i--) l[i] = (l[i] << 1) | (l[i - 1] >> 31);
+        l[0] <<= 1;
+    }
+    // Kaliski's almost-inverse (shift / add / subtract only, exactly k <= 2 * 254 iterations, no
+    // modular halving) followed by the 2^k correction as Montgomery products with one-bit constants:
+    // x = (aR)^-1 2^k  ->  x 2^512 (by R^3)  ->  / 2^k1  ->  / 2^k2   (k1 + k2 = k)  =  a^-1 R.
+    static __device__ Fp inv_kaliski(const Fp& a) {
+        Fp u = modulus(), v = a, r = zero(), s = zero(), d;
+        s.l[0] = 1;
+        uint32_t k = 0;
+        while (!v.is_zero() && k < 600) {
+            if (!(u.l[0] & 1u)) {
+                u.raw_shr1();
+                s.raw_shl1();
+            } else if (!(v.l[0] & 1u)) {
+                v.raw_shr1();
+                r.raw_shl1();
+            } else if (raw_sub_borrow(d, v, u) == 0) {     // v >= u (u == v == 1 ends the loop here)
+                v = d;
+                v.raw_shr1();
+                raw_add_to(s, r);
+                r.raw_shl1();
+            } else {
+                raw_sub_borrow(u, u, v);
+                u.raw_shr1();
+                raw_add_to(r, s);
+                s.raw_shl1();
+            }
+            k++;
+        }
+        if (r.geq_p()) r.raw_sub(modulus());
+        Fp x = modulus();
+        x.raw_sub(r);                                      // (aR)^-1 2^k mod p
+        Fp r3;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r3.l[i] = PR::r3(i);
+        x = mul(x, r3);
+        const uint32_t k1 = k < 256 ? k : 256, k2 = k - k1;
+        Fp c = zero();
+        c.l[(256 - k1) >> 5] = 1u << ((256 - k1) & 31);
+        if (k1 == 0) c = one();                            // unreachable for a != 0 (k >= 254)
+        x = mul(x, c);
+        if (k2) {
+            c = zero();
+            c.l[(256 - k2) >> 5] = 1u << ((256 - k2) & 31);
+            x = mul(x, c);
+        }
+        return x;
+    }
+#endif
 };
 
 using Fq = Fp<FqParams>;

@@ -11,6 +11,7 @@
 // SURVEY.md Appendix B.  The host only sequences phases, hashes the transcript and handles
 // a few scalars per phase; every vector operation runs in HIP kernels.
 #include <algorithm>
+#include <chrono>
 #include <map>
 
 #include "prover_kernels.cuh"
@@ -214,6 +215,7 @@ struct shp_prover {
     ShplonkArgs* shp_args = nullptr;
     Fr *blinds = nullptr, *ntt_tmp = nullptr;
     uint32_t* key = nullptr;
+    Fr* h_grid = nullptr;                                      // pinned host staging of the witness grid
     uint32_t* rank = nullptr;                                  // [2L][n] rank-sort scratch
     Fr *sc_pre = nullptr, *sc_suf = nullptr;                   // [SC][n] block-local scans
     Fr *sc_tot = nullptr;                                      // [6][SC][nb]: tot_a, tot_b, bpre_a, bsuf_b | [SC] inv
@@ -229,6 +231,7 @@ struct shp_prover {
     ~shp_prover() {
         for (void* p : owned) (void)hipFree(p);
         msm_ws.release();
+        if (h_grid) (void)hipHostFree(h_grid);
         if (own_stream && st) (void)hipStreamDestroy(st);
     }
 };
@@ -272,6 +275,7 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->ntt_tmp = pr->dalloc<Fr>((size_t)(NV + 1) * ne);
     pr->key = pr->dalloc<uint32_t>(8);
     pr->rank = pr->dalloc<uint32_t>((size_t)2 * L * n);
+    SHP_HIP(hipHostMalloc((void**)&pr->h_grid, (size_t)(P.num_advice + 1) * n * sizeof(Fr), hipHostMallocDefault));
     pr->sc_cnt = std::max<uint32_t>(S + L, MAX_POINTS);
     pr->sc_pre = pr->dalloc<Fr>((size_t)pr->sc_cnt * n);
     pr->sc_suf = pr->dalloc<Fr>((size_t)pr->sc_cnt * n);
@@ -282,10 +286,10 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
 
 // ------------------------------------------------------------------------------ host pieces
 // P1: the plan's witness program over Montgomery values (SURVEY.md row a7 `synthesize`)
-static void run_witness(const PlanData& P, const std::vector<Fr>& inputs, std::vector<Fr>& grid /* [A][n] */,
+static void run_witness(const PlanData& P, const std::vector<Fr>& inputs, Fr* grid /* [A][n], pinned */,
                         std::vector<Fr>& instances) {
     const uint32_t A = P.num_advice, n = P.n;
-    grid.assign((size_t)A * n, Fr::zero());
+    memset(grid, 0, (size_t)A * n * sizeof(Fr));
     std::vector<Fr> scratch(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
     auto cell = [&](uint32_t c, uint32_t r) -> Fr& { return c == A ? scratch[r] : grid[(size_t)c * n + r]; };
     for (const WOp& w : P.wops) {
@@ -392,6 +396,29 @@ static std::vector<Fr> interpolate(const std::vector<Fr>& xs, const std::vector<
     return out;
 }
 
+// host-side phase clock (SHP_PHASE_TRACE=1): wall time between phase marks, printed per proof
+namespace {
+struct PhaseClock {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    std::vector<std::pair<const char*, double>> marks;
+    PhaseClock() : on(getenv("SHP_PHASE_TRACE") != nullptr) { t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char* name) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        marks.push_back({name, std::chrono::duration<double, std::micro>(now - last).count()});
+        last = now;
+    }
+    ~PhaseClock() {
+        if (!on) return;
+        double tot = std::chrono::duration<double, std::micro>(last - t0).count();
+        fprintf(stderr, "[phases] total %.0f us:", tot);
+        for (auto& m : marks) fprintf(stderr, " %s=%.0f", m.first, m.second);
+        fprintf(stderr, "\n");
+    }
+};
+}  // namespace
+
 // ------------------------------------------------------------------------------ create_proof
 static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inputs, const uint8_t seed[32],
                        std::vector<uint8_t>& proof_out, std::vector<Fr>& instances_out) {
@@ -433,6 +460,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     uint64_t ctr = 0;
     auto draw = [&]() { return fr_draw(key, ctr++); };
 
+    PhaseClock pc;
     // ---- P0/P1: witness, blinding rows, instance column
     std::vector<Fr> inputs(n_inputs);
     for (size_t i = 0; i < n_inputs; i++) {
@@ -441,18 +469,23 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         SHP_REQUIRE(!raw.geq_p(), SHP_ERR_FORMAT, "prove: witness input is not a canonical field element");
         inputs[i] = Fr::from_raw(raw);
     }
-    std::vector<Fr> grid, instances;
+    std::vector<Fr> instances;
+    Fr* const grid = pr->h_grid;                        // pinned: [A][n] advice, then the instance column
     run_witness(P, inputs, grid, instances);
+    pc.mark("run_witness");
     for (uint32_t c = 0; c < A; c++)
         for (uint32_t r = u; r < n; r++) grid[(size_t)c * n + r] = draw();
+    pc.mark("blind_draws");
     ctr += A;                                           // one (unused) commitment blind per advice column
-    std::vector<Fr> instcol(n, Fr::zero());
+    Fr* const instcol = grid + (size_t)A * n;
+    memset(instcol, 0, (size_t)n * sizeof(Fr));
     for (size_t i = 0; i < instances.size(); i++) instcol[i] = instances[i];
-    SHP_HIP(hipMemcpyAsync(V(0), grid.data(), (size_t)A * n * sizeof(Fr), hipMemcpyHostToDevice, st));
-    SHP_HIP(hipMemcpyAsync(V(I_INST), instcol.data(), (size_t)n * sizeof(Fr), hipMemcpyHostToDevice, st));
+    SHP_HIP(hipMemcpyAsync(V(0), grid, (size_t)A * n * sizeof(Fr), hipMemcpyHostToDevice, st));
+    SHP_HIP(hipMemcpyAsync(V(I_INST), instcol, (size_t)n * sizeof(Fr), hipMemcpyHostToDevice, st));
     SHP_HIP(hipMemcpyAsync(pr->key, key, 32, hipMemcpyHostToDevice, st));
     Transcript tr(pk->vk_digest);
     for (auto& v : instances) tr.common_scalar(v);
+    pc.mark("witness+upload");
     // ---- P2: advice commitments.  The random polynomial of P7 depends on no challenge: its
     // coefficients (blinding stream position known up front) and its commitment ride in the same launch.
     const uint64_t ctr_rand = (uint64_t)A * nb + A + (uint64_t)L * (2 * nb + 2) + (uint64_t)(S + L) * (bf + 1);
@@ -478,6 +511,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         a.inst_base = CS(I_INST);
         a.size_mask = ne - 1; a.rot_step = estep;
     };
+    pc.mark("advice_msm");
     // ---- P3: lookups -- compress, permute, commit
     std::vector<Fr> hb;                                 // host staging of blinding values
     if (L) {
@@ -512,14 +546,17 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         SHP_HIP(hipMemsetAsync(pr->err, 0, 16, st));
         uint32_t nt = std::min<uint32_t>(1024, n);
         // sorted input of lookup l at sort_out[2l], sorted table at sort_out[2l+1]
+        hipLaunchKernelGGL(lookup_flags_kernel, dim3(ceil_div(u, 256), L), dim3(256), 0, st, pr->sort_out, pr->sort_out + n,
+                           (size_t)2 * n, u, n, pr->rank);
         hipLaunchKernelGGL(lookup_permute_kernel, dim3(L), dim3(nt), 0, st, pr->sort_out, pr->sort_out + n, (size_t)2 * n, u, n,
-                           V(I_PIN), V(I_PIN + 1), (size_t)2 * n, pr->rep_scratch, pr->blinds, pr->err);
+                           V(I_PIN), V(I_PIN + 1), (size_t)2 * n, pr->rep_scratch, pr->rank, pr->blinds, pr->err);
         uint32_t herr = 0;
         msm_run_ws(srs->msm_gl, pr->msm_ws, V(I_PIN), n, n, 2 * L, pts.data(), st);
         SHP_HIP(hipMemcpy(&herr, pr->err, 4, hipMemcpyDeviceToHost));
         SHP_REQUIRE(herr == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
         for (uint32_t i = 0; i < 2 * L; i++) tr.write_point(pts[i].x, pts[i].y);
     }
+    pc.mark("lookup");
     // ---- P4
     const Fr beta = tr.squeeze();
     const Fr gamma = tr.squeeze();
@@ -553,6 +590,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     msm_run_ws(srs->msm_gl, pr->msm_ws, V(I_PZ), n, n, S + L, pts.data(), st);
     for (uint32_t i = 0; i < S + L; i++) tr.write_point(pts[i].x, pts[i].y);
     tr.write_point(rand_comm.x, rand_comm.y);
+    pc.mark("products_msm");
     // ---- P8
     const Fr y = tr.squeeze();
     // ---- P9: coefficient forms and cosets of everything committed so far (+ instance column)
@@ -608,6 +646,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     ctr += npieces;                                      // one (unused) blind per quotient piece
     msm_run_ws(srs->msm_g, pr->msm_ws, pr->h, n, n, npieces, pts.data(), st);
     for (uint32_t i = 0; i < npieces; i++) tr.write_point(pts[i].x, pts[i].y);
+    pc.mark("quotient_msm");
     // ---- P11: evaluations
     const Fr x = tr.squeeze();
     std::vector<int32_t> superset;
@@ -677,6 +716,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     std::map<std::pair<PolyKey, int32_t>, Fr> ev;
     for (size_t i = 0; i < jobs.size(); i++) ev[job_key[i]] = evals[i];
     for (size_t i = 0; i < n_proof_evals; i++) tr.write_scalar(evals[i]);
+    pc.mark("evals");
     // ---- P12: SHPLONK, W
     const Fr zeta_c = tr.squeeze();
     const Fr nu = tr.squeeze();
@@ -732,6 +772,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     hipLaunchKernelGGL(shplonk_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals);
     msm_run_ws(srs->msm_gl, pr->msm_ws, pr->wvals, n, n, 1, pts.data(), st);
     tr.write_point(pts[0].x, pts[0].y);
+    pc.mark("W");
     // ---- P13: W'
     const Fr mu = tr.squeeze();
     Fr zt = Fr::one();
@@ -763,6 +804,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     hipLaunchKernelGGL(shplonk_wp_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals + n);
     msm_run_ws(srs->msm_gl, pr->msm_ws, pr->wvals + n, n, n, 1, pts.data(), st);
     tr.write_point(pts[0].x, pts[0].y);
+    pc.mark("Wprime");
     SHP_HIP(hipGetLastError());
     pr->proofs_done++;
     proof_out.swap(tr.proof);

@@ -295,6 +295,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void batch_invert_apply_kernel(const 
 // (halo2 lookup::prover::permute_expression_pair) -- all on device:
 // rank sort of the usable rows (n^2 / 2 comparisons are cheap at n = 2^13), then flags,
 // prefix sums and binary searches in one workgroup.
+// a < b as 256-bit integers: the borrow of a - b (one carry chain, no branches)
+__device__ __forceinline__ bool raw_less(const Fr& a, const Fr& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    Fr d;
+    return Fr::raw_sub_borrow(d, a, b) != 0;
+#else
+    return Fr::raw_lt(a, b);
+#endif
+}
 __device__ __forceinline__ int raw_cmp(const Fr& a, const Fr& b) {
 #pragma unroll
     for (int i = 7; i >= 0; i--) {
@@ -311,7 +320,7 @@ __global__ void to_raw_kernel(const Fr* in, Fr* out, uint32_t count) {
 
 // rank sort, spread over the chip: blockIdx.x = tile of 256 elements, blockIdx.y = array,
 // blockIdx.z = slice of the comparison range; partial ranks meet in `rank` (zeroed by the caller)
-constexpr uint32_t RANK_SLICE = 512;
+constexpr uint32_t RANK_SLICE = 256;
 __global__ __launch_bounds__(256) void rank_count_kernel(const Fr* raw, uint32_t* rank, uint32_t u, size_t stride) {
     __shared__ Fr tile[256];
     const Fr* src = raw + (size_t)blockIdx.y * stride;
@@ -326,9 +335,11 @@ __global__ __launch_bounds__(256) void rank_count_kernel(const Fr* raw, uint32_t
         if (j < s1) tile[threadIdx.x] = ld(src + j);
         __syncthreads();
         const uint32_t lim = s1 - base < 256 ? s1 - base : 256;
+        // element j precedes mine iff (x_j, j) < (mine, i): x_j < mine, or not (mine < x_j) and j < i
         for (uint32_t k = 0; k < lim; k++) {
-            int c = raw_cmp(tile[k], mine);
-            r += (c < 0 || (c == 0 && base + k < i)) ? 1u : 0u;
+            const Fr x = tile[k];
+            const bool before = base + k < i ? !raw_less(mine, x) : raw_less(x, mine);
+            r += before ? 1u : 0u;
         }
     }
     if (i < u && r) atomicAdd(rank + (size_t)blockIdx.y * stride + i, r);
@@ -369,11 +380,34 @@ __device__ __forceinline__ uint32_t block_scan_u32_excl(uint32_t v, uint32_t* sh
     return r;
 }
 
+// flags of the sorted input a / sorted table tb (raw), one lane per usable row, whole chip:
+//   bit 0  a[i] is the first of its run          bit 1  that first occurrence is missing from the table
+//   bit 2  tb[i] stays in the leftover list (it is not the first of a run that the input also holds)
+__global__ __launch_bounds__(256) void lookup_flags_kernel(const Fr* a_all, const Fr* tb_all, size_t sstride, uint32_t u,
+                                                           uint32_t n, uint32_t* flags_all) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
+    if (i >= u) return;
+    const Fr* a = a_all + (size_t)l * sstride;
+    const Fr* tb = tb_all + (size_t)l * sstride;
+    const Fr ai = ld(a + i), ti = ld(tb + i);
+    uint32_t f = 0;
+    const bool first = i == 0 || raw_cmp(ld(a + i - 1), ai) != 0;
+    if (first) {
+        f |= 1u;
+        if (!bsearch_raw(tb, u, ai)) f |= 2u;
+    }
+    const bool tfirst = i == 0 || raw_cmp(ld(tb + i - 1), ti) != 0;
+    if (!(tfirst && bsearch_raw(a, u, ti))) f |= 4u;
+    flags_all[(size_t)l * n + i] = f;
+}
+
 // a = sorted input (raw), tb = sorted table (raw); writes permuted input / table (Montgomery)
 // rows [0,u) and the blinding rows [u,n) of both; err[0] != 0 when the input is not in the table.
+// One workgroup per lookup: only prefix sums over the flags and the scatter are left here.
 __global__ __launch_bounds__(1024) void lookup_permute_kernel(const Fr* a_all, const Fr* tb_all, size_t sstride, uint32_t u,
                                                               uint32_t n, Fr* pin_all, Fr* ptab_all, size_t pstride,
-                                                              uint32_t* scratch_all, const Fr* blinds, uint32_t* err) {
+                                                              uint32_t* scratch_all, const uint32_t* flags_all, const Fr* blinds,
+                                                              uint32_t* err) {
     __shared__ uint32_t sh[1024];
     const uint32_t l = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
     const Fr* a = a_all + (size_t)l * sstride;
@@ -381,44 +415,36 @@ __global__ __launch_bounds__(1024) void lookup_permute_kernel(const Fr* a_all, c
     Fr* pin = pin_all + (size_t)l * pstride;
     Fr* ptab = ptab_all + (size_t)l * pstride;
     uint32_t* rep = scratch_all + (size_t)l * n;        // rows of repeated inputs, ascending
+    const uint32_t* fl = flags_all + (size_t)l * n;
     const uint32_t per = (u + nt - 1) / nt;
-    const uint32_t r0 = t * per, r1 = r0 + per < u ? r0 + per : u;
-    // pass 1: count repeated input rows / kept table entries in my range
-    uint32_t nrep = 0, nkeep = 0;
+    const uint32_t r0 = t * per < u ? t * per : u, r1 = r0 + per < u ? r0 + per : u;
+    uint32_t nrep = 0, nkeep = 0, bad = 0;
     for (uint32_t i = r0; i < r1; i++) {
-        Fr ai = ld(a + i);
-        bool first = i == 0 || raw_cmp(ld(a + i - 1), ai) != 0;
-        if (!first) nrep++;
-        else if (!bsearch_raw(tb, u, ai)) atomicAdd(err, 1u);
-        Fr ti = ld(tb + i);
-        bool tfirst = i == 0 || raw_cmp(ld(tb + i - 1), ti) != 0;
-        bool removed = tfirst && bsearch_raw(a, u, ti);
-        if (!removed) nkeep++;
+        const uint32_t f = fl[i];
+        nrep += (f & 1u) ? 0u : 1u;
+        bad += (f >> 1) & 1u;
+        nkeep += (f >> 2) & 1u;
     }
+    if (bad) atomicAdd(err, bad);
     uint32_t tot_rep, tot_keep;
     uint32_t rep_off = block_scan_u32_excl(nrep, sh, t, nt, &tot_rep);
     uint32_t keep_off = block_scan_u32_excl(nkeep, sh, t, nt, &tot_keep);
     if (t == 0 && tot_rep != tot_keep) atomicAdd(err, 1u);
-    // pass 2: list the repeated rows; write first occurrences
+    // list the repeated rows; write first occurrences
     uint32_t q = rep_off;
     for (uint32_t i = r0; i < r1; i++) {
-        Fr ai = ld(a + i);
-        bool first = i == 0 || raw_cmp(ld(a + i - 1), ai) != 0;
-        Fr am = Fr::from_raw(ai);
+        const Fr am = Fr::from_raw(ld(a + i));
         st(pin + i, am);
-        if (first) st(ptab + i, am);
+        if (fl[i] & 1u) st(ptab + i, am);
         else rep[q++] = i;
     }
     __threadfence_block();
     __syncthreads();
-    // pass 3: leftover table entries (ascending) go to the repeated rows taken from the END
+    // leftover table entries (ascending) go to the repeated rows taken from the END
     q = keep_off;
     for (uint32_t i = r0; i < r1; i++) {
-        Fr ti = ld(tb + i);
-        bool tfirst = i == 0 || raw_cmp(ld(tb + i - 1), ti) != 0;
-        bool removed = tfirst && bsearch_raw(a, u, ti);
-        if (!removed) {
-            if (q < tot_rep) st(ptab + rep[tot_rep - 1 - q], Fr::from_raw(ti));
+        if (fl[i] & 4u) {
+            if (q < tot_rep) st(ptab + rep[tot_rep - 1 - q], Fr::from_raw(ld(tb + i)));
             q++;
         }
     }
