@@ -26,7 +26,6 @@ import json
 import os
 import random
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -120,43 +119,22 @@ def main():
     wits = [b"".join(int(x).to_bytes(32, "little")
                      for x in circuits.withdraw_witness_inputs(lay, shp.poseidon2_hash_host, rnd))
             for _ in range(max(a.lanes, 4))]
-    provers = [shp.Prover(pk) for _ in range(a.lanes)]
+    # the native proving pool: a.lanes lanes (HIP stream + HBM workspace each) behind one FIFO queue,
+    # fed by C++ worker threads; one step = ONE shp_prove_batch call of lanes x proofs-per-lane proofs
+    pool = shp.Pool(pk, a.lanes)
+    provers = [pool.lane(i) for i in range(a.lanes)]
+    per_step = a.lanes * a.proofs_per_lane
+    import ctypes
+    wit_blob = b"".join(wits[i % len(wits)] for i in range(per_step))
+    proofs_buf = ctypes.create_string_buffer(pk.proof_len * per_step)
+    lens_buf = (ctypes.c_size_t * per_step)()
     counter = [0]
 
-    # persistent lane threads; a step releases all lanes once and waits for them
-    go = [threading.Semaphore(0) for _ in provers]
-    done = threading.Semaphore(0)
-    stop = [False]
-    errors = []
-
-    def lane(i):
-        pr = provers[i]
-        j = 0
-        while True:
-            go[i].acquire()
-            if stop[0]:
-                return
-            try:
-                for _ in range(a.proofs_per_lane):
-                    seed = ((rank << 40) | (i << 32) | j).to_bytes(32, "little")
-                    pr.prove_bytes(wits[(i + j) % len(wits)], seed)
-                    j += 1
-            except Exception as e:      # noqa: BLE001
-                errors.append(e)
-            done.release()
-
-    threads = [threading.Thread(target=lane, args=(i,), daemon=True) for i in range(a.lanes)]
-    for t in threads:
-        t.start()
-
     def step():
-        for g in go:
-            g.release()
-        for _ in provers:
-            done.acquire()
-        counter[0] += len(provers) * a.proofs_per_lane
-        if errors:
-            raise errors[0]
+        j = counter[0]
+        seeds = b"".join(((rank << 40) | (j + i)).to_bytes(32, "little") for i in range(per_step))
+        pool.prove_batch_raw(wit_blob, seeds, per_step, proofs_buf, lens_buf)
+        counter[0] += per_step
 
     sync = torch.cuda.synchronize
     barrier = dist.barrier if dist else (lambda: None)
@@ -187,10 +165,7 @@ def main():
         lat.append(time.perf_counter() - s)
     lat.sort()
 
-    stop[0] = True
-    for g in go:
-        g.release()
-
+    assert all(lens_buf[i] == pk.proof_len for i in range(per_step)), "a proof of the last step is missing"
     if rank == 0:
         n = 1 << 13
         # dominant kernel family of the timed region, by summed HIP-event time
@@ -206,6 +181,16 @@ def main():
                      "rank_sort": 2 * 2 * n * 32, "ntt_pass": 64 * 65536}.get(name, msm_launch_bytes)
         avg_s = (ms / cnt) * 1e-3 if cnt else float("inf")
         achieved = alg_bytes / avg_s / 1e9 if cnt else 0.0
+        # HBM bytes per launch of that kernel from the PMC passes of this same command (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 correction on FETCH_SIZE: profiles/README.md)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_bench.json")))
+            ent = pmc.get(name + "_kernel")
+            if ent:
+                traffic = ent["fetch_bytes_per_launch_x2corr"] + ent["write_bytes_per_launch"]
+        except OSError:
+            pass
         out = {
             "metric": "Shielder proofs/sec (whole node), 2^13 withdraw-shaped circuit",
             "value": total_proofs / elapsed,
@@ -224,10 +209,14 @@ def main():
                        "parallelism": f"proofs sharded over {n_gpus} GPU(s), no collective"},
             "p50_latency_ms": 1e3 * lat[len(lat) // 2] if lat else None,
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "avg_launch_us": 1e6 * avg_s if cnt else None, "launches_per_proof": launches_per_proof,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "k=13 kernels are integer-ALU/latency bound, not HBM bound (DESIGN.md Rooflines)"},
+                         "note": "k=13 kernels are bound by the 32-bit integer ALU, not by HBM (DESIGN.md section 3); the direct-table "
+                                 "MSM deliberately gathers one 64 B table entry per non-zero digit (traffic >> algorithmic bytes) "
+                                 "to remove all bucket arithmetic",
+                         "alu": {"fr_mul_ceiling_per_s": ctx.fr_mul_rate(2048),
+                                 "unit": "254-bit Montgomery products/s, every CU busy (tools/ubench, shp_diag_fr_mul_rate)"}},
             "kernel_ms_per_proof": {k_: v[1] / max(1, a.steps * proofs_per_step) for k_, v in sorted(prof.items())},
         }
         if world == 1 and a.cpu_proofs > 0:

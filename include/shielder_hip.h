@@ -42,7 +42,8 @@ enum {
     SHP_ERR_HIP = 3,
     SHP_ERR_FORMAT = 4,       /* malformed ptau / RawBytes / plan / non-canonical field element */
     SHP_ERR_INTERNAL = 5,
-    SHP_ERR_UNSATISFIED = 6   /* witness does not satisfy the circuit (lookup input not in table) */
+    SHP_ERR_UNSATISFIED = 6,  /* witness does not satisfy the circuit (lookup input not in table) */
+    SHP_ERR_BUSY = 7          /* proving pool queue full (the reference's task pool answers HTTP 504 there) */
 };
 
 #define SHP_BASIS_MONOMIAL 0  /* Params::commit          : MSM over g          */
@@ -53,6 +54,7 @@ typedef struct shp_srs shp_srs;   /* device-resident KZG SRS ("Params") */
 typedef struct shp_msm shp_msm;   /* fixed-base MSM plan over one table of bases */
 typedef struct shp_pk shp_pk;     /* device-resident proving key ("ProvingKey" + its VerifyingKey) */
 typedef struct shp_prover shp_prover; /* one proving lane: a HIP stream + its workspace in HBM */
+typedef struct shp_pool shp_pool;     /* N proving lanes behind one bounded FIFO queue */
 
 /* ---- library / device ------------------------------------------------------------ */
 const char* shp_last_error(void);
@@ -169,6 +171,30 @@ int32_t shp_prover_profile_read(shp_prover* p, uint32_t index, const char** name
                                 double* total_ms);
 /* poseidon::off_circuit::hash on the host (shielder_bindings/src/hash.rs:17-26): 32-byte LE canonical */
 int32_t shp_poseidon2_hash_host(const uint8_t* inputs_le32, uint32_t arity, uint8_t out_le32[32]);
+
+/* ---- proving pool: the "whole node" serve path ----------------------------------------
+ * Replaces the reference's per-connection proving tasks behind a bounded task pool
+ * (/root/reference/tee/crates/shielder-prover-tee/src/main.rs:13-20, server.rs:157-195;
+ *  tee/crates/shielder-prover-server/src/main.rs:42-45, command_line_args.rs:23-28): `lanes` proving
+ * lanes of one device-resident key, fed by worker threads from a FIFO queue of at most
+ * `queue_cap` (0 = 100, the reference's default) pending jobs. */
+int32_t shp_pool_create(shp_pk* pk, uint32_t lanes, uint32_t queue_cap, shp_pool** out);
+int32_t shp_pool_destroy(shp_pool* p);        /* drains the queue, joins the workers, frees the lanes */
+int32_t shp_pool_lanes(const shp_pool* p, uint32_t* lanes);
+int32_t shp_pool_lane(shp_pool* p, uint32_t index, shp_prover** lane);   /* e.g. for shp_prover_profile */
+/* asynchronous: enqueue one proof (arguments as shp_prove; the witness is copied), SHP_ERR_BUSY when
+ * the queue is full; collect it with shp_pool_wait, which returns the proof's own status */
+int32_t shp_pool_submit(shp_pool* p, const uint8_t* witness_le32, size_t n_inputs, const uint8_t seed[32], uint64_t* ticket);
+int32_t shp_pool_wait(shp_pool* p, uint64_t ticket, uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
+                      uint8_t* instances_le32, size_t instances_cap);
+/* synchronous batch of `count` independent proofs over the pool's lanes: witness i at
+ * witnesses_le32 + i * n_inputs * 32, seed i at seeds + 32 i, proof i at proofs_out + i * proof_stride
+ * (length in proof_lens[i]), public inputs i at instances_le32 + i * instances_stride (optional).
+ * Returns the first failing proof's status (the others are still produced). */
+int32_t shp_prove_batch(shp_pool* p, const uint8_t* witnesses_le32, size_t n_inputs, size_t count, const uint8_t* seeds,
+                        uint8_t* proofs_out, size_t proof_stride, size_t* proof_lens, uint8_t* instances_le32,
+                        size_t instances_stride);
+int32_t shp_pool_stats(const shp_pool* p, uint64_t* proofs_done, uint64_t* queued);
 
 /* ---- diagnostics ------------------------------------------------------------------- */
 /* sustained Fr Montgomery products per second with every CU busy: the integer-ALU ceiling that

@@ -108,3 +108,40 @@ def test_error_paths(shp, oracle, gpu_ctx):
         tpr.prove([99, 99], bytes(32))
     assert e.value.code == 6
     tpr.close(); tpk.close(); tparams.close()
+
+
+def test_pool_batch_equals_single_lane(shp, oracle, gpu_ctx):
+    """shp_pool / shp_prove_batch (the "whole node" serve path): a batch sharded over lanes gives,
+    proof for proof, the bytes of a single lane and of the oracle; submit/wait and the error path"""
+    PL, C, plan, lay, osrs, opk, params, pk = setup(shp, oracle, gpu_ctx, True)
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    rnd = random.Random(77)
+    count = 7
+    wits = [C.withdraw_witness_inputs(lay, H, rnd, 2**31 + i, 2**20 + i) for i in range(count)]
+    blobs = [b"".join(int(x).to_bytes(32, "little") for x in w) for w in wits]
+    seeds = [bytes([i + 1]) * 32 for i in range(count)]
+    pool = shp.Pool(pk, 3)
+    got = pool.prove_batch(b"".join(blobs), b"".join(seeds), count)
+    single = shp.Prover(pk)
+    for i in range(count):
+        p1, i1 = single.prove_bytes(blobs[i], seeds[i])
+        assert got[i] == (p1, i1), f"batch proof {i} differs from the single-lane proof"
+    oproof, oinst = PL.prove(opk, osrs, wits[3], seeds[3])
+    assert got[3] == (oproof, oinst)
+    assert PL.verify(opk, got[5][0], got[5][1], tau=TAU)
+    # asynchronous tickets, collected out of order
+    t = [pool.submit(blobs[i], seeds[i]) for i in range(4)]
+    for i in (2, 0, 3, 1):
+        assert pool.wait(t[i]) == got[i]
+    # a non-canonical witness fails its own ticket with SHP_ERR_FORMAT and leaves the pool usable
+    bad = bytearray(blobs[0]); bad[0:32] = R.to_bytes(32, "little")
+    tb = pool.submit(bytes(bad), seeds[0])
+    with pytest.raises(shp.ShpError) as e:
+        pool.wait(tb)
+    assert e.value.code == 4
+    with pytest.raises(shp.ShpError):
+        pool.prove_batch(bytes(bad) + blobs[1], seeds[0] + seeds[1], 2)
+    assert pool.wait(pool.submit(blobs[1], seeds[1])) == got[1]
+    done, queued = pool.stats()
+    assert done >= count + 8 and queued == 0
+    pool.close(); single.close(); pk.close(); params.close()

@@ -337,3 +337,68 @@ class Prover:
         if self.h:
             lib().shp_prover_destroy(self.h)
             self.h = C.c_void_p()
+
+
+class Pool:
+    """N proving lanes of one device-resident key behind a bounded FIFO queue (shp_pool): the native
+    serve path -- replaces the TEE's per-connection proving tasks
+    (/root/reference/tee/crates/shielder-prover-tee/src/main.rs:13-20, server.rs:157-195)."""
+
+    def __init__(self, pk: ProvingKey, lanes: int, queue_cap: int = 0):
+        self.pk = pk
+        self.lanes = lanes
+        self.h = C.c_void_p()
+        _check(lib().shp_pool_create(pk.h, C.c_uint32(lanes), C.c_uint32(queue_cap), C.byref(self.h)))
+
+    def lane(self, i):
+        """borrowed Prover view of lane i (profiling); do not close it"""
+        pr = Prover.__new__(Prover)
+        pr.pk = self.pk
+        pr.h = C.c_void_p()
+        _check(lib().shp_pool_lane(self.h, C.c_uint32(i), C.byref(pr.h)))
+        pr.close = lambda: None
+        return pr
+
+    def submit(self, wit: bytes, seed: bytes) -> int:
+        t = C.c_uint64()
+        _check(lib().shp_pool_submit(self.h, C.c_char_p(wit), C.c_size_t(len(wit) // 32), C.c_char_p(seed), C.byref(t)))
+        return t.value
+
+    def wait(self, ticket: int):
+        proof = C.create_string_buffer(self.pk.proof_len)
+        plen = C.c_size_t()
+        inst = C.create_string_buffer(32 * self.pk.n_instances)
+        _check(lib().shp_pool_wait(self.h, C.c_uint64(ticket), proof, C.c_size_t(self.pk.proof_len), C.byref(plen), inst,
+                                   C.c_size_t(len(inst.raw))))
+        return proof.raw[:plen.value], [int.from_bytes(inst.raw[32 * i:32 * i + 32], "little") for i in range(self.pk.n_instances)]
+
+    def prove_batch(self, wits: bytes, seeds: bytes, count: int):
+        """count proofs: wits = count witnesses back to back, seeds = count x 32 bytes -> [(proof, instances)]"""
+        n_in = len(wits) // 32 // count
+        stride, istride = self.pk.proof_len, 32 * self.pk.n_instances
+        proofs = C.create_string_buffer(stride * count)
+        insts = C.create_string_buffer(max(1, istride * count))
+        lens = (C.c_size_t * count)()
+        _check(lib().shp_prove_batch(self.h, C.c_char_p(wits), C.c_size_t(n_in), C.c_size_t(count), C.c_char_p(seeds), proofs,
+                                     C.c_size_t(stride), lens, insts, C.c_size_t(istride)))
+        out = []
+        for i in range(count):
+            ins = [int.from_bytes(insts.raw[istride * i + 32 * j: istride * i + 32 * j + 32], "little") for j in range(self.pk.n_instances)]
+            out.append((proofs.raw[stride * i: stride * i + lens[i]], ins))
+        return out
+
+    def prove_batch_raw(self, wits: bytes, seeds: bytes, count: int, proofs_buf, lens_buf):
+        """same without unpacking (bench): buffers are caller-owned ctypes arrays"""
+        n_in = len(wits) // 32 // count
+        _check(lib().shp_prove_batch(self.h, C.c_char_p(wits), C.c_size_t(n_in), C.c_size_t(count), C.c_char_p(seeds), proofs_buf,
+                                     C.c_size_t(self.pk.proof_len), lens_buf, None, C.c_size_t(0)))
+
+    def stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().shp_pool_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self.h:
+            lib().shp_pool_destroy(self.h)
+            self.h = C.c_void_p()

@@ -427,6 +427,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     shp_srs* srs = pk->srs;
     const PlanData& P = pk->plan;
     hipStream_t st = pr->st;
+    SHP_HIP(hipSetDevice(ctx->device));                 // the caller may be any host thread (pool workers, FFI callers)
     const uint32_t n = pk->n, ne = pk->ne, k = P.k, ek = P.ext_k, bf = P.bf, u = P.usable;
     const uint32_t A = P.num_advice, L = (uint32_t)P.lookups.size(), S = P.num_sets, NV = pk->NV;
     const uint32_t PC = (uint32_t)P.perm_cols.size(), F = P.num_fixed;
