@@ -80,6 +80,15 @@ int32_t shp_download(shp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
 int32_t shp_fr_from_le32(const uint8_t in[32], uint64_t out[4]);
 int32_t shp_fr_to_le32(const uint64_t in[4], uint8_t out[32]);
 
+/* halo2_verifier::encode_calldata(proof, instances)
+ * (/root/reference/crates/halo2-verifier/src/lib/verifier_contract.rs:6-20): ABI encoding of
+ * Halo2Verifier.verifyProof(bytes proof, uint256[] instances), selector 0x1e8e1e13 -- the bytes the
+ * reference's callers put on chain (contracts/Shielder.sol:372,521,703 forward them).  Host only.
+ * instances_le32 = the canonical little-endian public inputs shp_prove returns; out == NULL only
+ * reports the length. */
+int32_t shp_encode_calldata(const uint8_t* proof, size_t proof_len, const uint8_t* instances_le32, size_t n_instances,
+                            uint8_t* out, size_t out_cap, size_t* out_len);
+
 /* ---- NTT over Fr  (halo2 EvaluationDomain: best_fft / lagrange_to_coeff / coeff_to_extended;
  *      conventions pinned by resources/ppot_0080_11_raw and Halo2Verifier.sol:475) ------ */
 /* `batch` polynomials of 2^log_n elements each, contiguous, in place, natural order in and out.
@@ -143,6 +152,12 @@ int32_t shp_srs_commit(shp_srs* srs, int32_t basis, const void* d_polys, uint32_
  * computed on the GPU. */
 int32_t shp_keygen(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan, size_t plan_len, shp_pk** out);
 int32_t shp_pk_destroy(shp_pk* pk);
+/* marshall_pk / unmarshall_pk (/root/reference/crates/shielder_bindings/build.rs:24-32,
+ * src/circuits/mod.rs:38-46).  The saved key is the plan + verifying-key material (commitments, digest):
+ * everything else is rebuilt on the GPU at load time in milliseconds, with no MSM.  out == NULL only
+ * reports the length.  shp_pk_load fails with SHP_ERR_FORMAT when the digest does not bind the parts. */
+int32_t shp_pk_save(const shp_pk* pk, uint8_t* out, size_t out_cap, size_t* out_len);
+int32_t shp_pk_load(shp_ctx* ctx, shp_srs* srs, const uint8_t* bytes, size_t len, shp_pk** out);
 int32_t shp_pk_info(const shp_pk* pk, uint32_t* k, uint32_t* n_witness_inputs, uint32_t* n_instances,
                     uint32_t* proof_len);
 /* verifying-key material: transcript digest, fixed and permutation commitments (64 B affine each) */

@@ -59,3 +59,21 @@ def test_product_does_not_reference_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace(
                     "never imports `oracle/`", ""), f
+
+
+def test_encode_calldata_matches_abi_encoding(shp, oracle):
+    """halo2_verifier::encode_calldata (crates/halo2-verifier/src/lib/verifier_contract.rs:6-20): selector of
+    verifyProof(bytes,uint256[]) and the head/tail ABI layout, against an independent encoding"""
+    import pytest
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    sel = oracle.keccak256(b"verifyProof(bytes,uint256[])")[:4]
+    assert sel.hex() == "1e8e1e13"
+    for plen, inst in ((0, []), (1, [0]), (64, [1, 2, 3]), (3456, [R - 1, 5, 2**200 + 7, 0, 1, 2, 3, 4])):
+        proof = bytes((i * 7 + 3) & 0xFF for i in range(plen))
+        pad = (plen + 31) // 32 * 32
+        want = (sel + (64).to_bytes(32, "big") + (96 + pad).to_bytes(32, "big") + plen.to_bytes(32, "big") + proof
+                + bytes(pad - plen) + len(inst).to_bytes(32, "big") + b"".join(x.to_bytes(32, "big") for x in inst))
+        assert shp.encode_calldata(proof, inst) == want
+    with pytest.raises(shp.ShpError) as e:
+        shp.encode_calldata(b"\x01", [R])
+    assert e.value.code == 4

@@ -272,13 +272,29 @@ def poseidon2_hash_host(ints):
 class ProvingKey:
     """Device-resident proving key of one circuit plan (the reference's `ProvingKey` + vk)."""
 
-    def __init__(self, ctx: Context, params: Params, plan: bytes):
+    def __init__(self, ctx: Context, params: Params, plan: bytes = None, saved: bytes = None):
+        """generate_keys_with_min_k (plan given) or unmarshall_pk (saved = bytes of save())"""
         self.ctx, self.params = ctx, params
         self.h = C.c_void_p()
-        _check(lib().shp_keygen(ctx.h, params.h, C.c_char_p(plan), C.c_size_t(len(plan)), C.byref(self.h)))
+        if saved is not None:
+            _check(lib().shp_pk_load(ctx.h, params.h, C.c_char_p(saved), C.c_size_t(len(saved)), C.byref(self.h)))
+        else:
+            _check(lib().shp_keygen(ctx.h, params.h, C.c_char_p(plan), C.c_size_t(len(plan)), C.byref(self.h)))
         k, ni, nins, pl = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         _check(lib().shp_pk_info(self.h, C.byref(k), C.byref(ni), C.byref(nins), C.byref(pl)))
         self.k, self.n_inputs, self.n_instances, self.proof_len = k.value, ni.value, nins.value, pl.value
+
+    @classmethod
+    def load(cls, ctx, params, saved: bytes):
+        return cls(ctx, params, saved=saved)
+
+    def save(self) -> bytes:
+        """marshall_pk: plan + verifying-key material (the rest is rebuilt on the GPU at load time)"""
+        n = C.c_size_t()
+        _check(lib().shp_pk_save(self.h, None, C.c_size_t(0), C.byref(n)))
+        out = C.create_string_buffer(n.value)
+        _check(lib().shp_pk_save(self.h, out, C.c_size_t(n.value), C.byref(n)))
+        return out.raw[:n.value]
 
     def vk_digest(self) -> bytes:
         out = C.create_string_buffer(32)
@@ -337,6 +353,19 @@ class Prover:
         if self.h:
             lib().shp_prover_destroy(self.h)
             self.h = C.c_void_p()
+
+
+def encode_calldata(proof: bytes, instances) -> bytes:
+    """halo2_verifier::encode_calldata: calldata of Halo2Verifier.verifyProof(bytes,uint256[])
+    (/root/reference/crates/halo2-verifier/src/lib/verifier_contract.rs:13-20)"""
+    ins = b"".join(int(x).to_bytes(32, "little") for x in instances)
+    n = C.c_size_t()
+    _check(lib().shp_encode_calldata(C.c_char_p(proof), C.c_size_t(len(proof)), C.c_char_p(ins), C.c_size_t(len(instances)),
+                                     None, C.c_size_t(0), C.byref(n)))
+    out = C.create_string_buffer(n.value)
+    _check(lib().shp_encode_calldata(C.c_char_p(proof), C.c_size_t(len(proof)), C.c_char_p(ins), C.c_size_t(len(instances)),
+                                     out, C.c_size_t(n.value), C.byref(n)))
+    return out.raw[:n.value]
 
 
 class Pool:

@@ -4,6 +4,7 @@
 
 #include <stdlib.h>
 #include "engine.hpp"
+#include "hostcrypto.hpp"
 
 namespace shp {
 
@@ -257,6 +258,39 @@ int32_t shp_fr_to_le32(const uint64_t in[4], uint8_t out[32]) {
         memcpy(m.l, in, 32);
         Fr raw = m.to_raw();
         memcpy(out, raw.l, 32);
+    });
+}
+
+int32_t shp_encode_calldata(const uint8_t* proof, size_t proof_len, const uint8_t* instances_le32, size_t n_instances,
+                            uint8_t* out, size_t out_cap, size_t* out_len) {
+    return guarded([&] {
+        SHP_REQUIRE(proof && out_len && (instances_le32 || n_instances == 0), SHP_ERR_INVALID_ARG, "encode_calldata: null argument");
+        const size_t padded = (proof_len + 31) / 32 * 32;
+        const size_t total = 4 + 64 + 32 + padded + 32 + 32 * n_instances;
+        *out_len = total;
+        if (!out) return;                                  // size query
+        SHP_REQUIRE(out_cap >= total, SHP_ERR_INVALID_ARG, "encode_calldata: buffer too small");
+        memset(out, 0, total);
+        static const char sig[] = "verifyProof(bytes,uint256[])";
+        uint8_t h[32];
+        keccak256(reinterpret_cast<const uint8_t*>(sig), sizeof(sig) - 1, h);
+        memcpy(out, h, 4);
+        auto put_u256 = [&](size_t off, uint64_t v) {
+            for (int i = 0; i < 8; i++) out[off + 31 - i] = (uint8_t)(v >> (8 * i));
+        };
+        uint8_t* body = out + 4;
+        put_u256(4 + 0, 64);                               // offset of `proof`
+        put_u256(4 + 32, 64 + 32 + padded);                // offset of `instances`
+        put_u256(4 + 64, proof_len);
+        memcpy(body + 96, proof, proof_len);
+        const size_t io = 4 + 96 + padded;
+        put_u256(io, n_instances);
+        for (size_t i = 0; i < n_instances; i++) {
+            Fr raw;
+            memcpy(raw.l, instances_le32 + 32 * i, 32);
+            SHP_REQUIRE(!raw.geq_p(), SHP_ERR_FORMAT, "encode_calldata: public input is not a canonical field element");
+            for (int b = 0; b < 32; b++) out[io + 32 + 32 * i + b] = instances_le32[32 * i + 31 - b];   // uint256 big-endian
+        }
     });
 }
 

@@ -66,6 +66,10 @@ inline void PlanData::parse(const uint8_t* d, size_t len) {
     n_wscratch = h[18];
     const uint32_t nim = h[19];
     SHP_REQUIRE(k >= 4 && k <= 20 && degree >= 3 && degree <= 16 && bf >= 3 && bf < 64, SHP_ERR_FORMAT, "plan: bad header");
+    // counts are bounded before anything is sized from them (a corrupted header must not allocate)
+    SHP_REQUIRE(num_advice >= 1 && num_advice <= 1024 && num_fixed <= 1024 && num_instance <= 1024 && nlk <= 64 && npc <= 1024 &&
+                    n_winputs <= (1u << 20) && n_wscratch <= (1u << 24),
+                SHP_ERR_FORMAT, "plan: implausible column / lookup counts");
     n = 1u << k;
     size_t off = 84;
     auto need = [&](size_t bytes) { SHP_REQUIRE(off + bytes <= len, SHP_ERR_FORMAT, "plan: truncated"); };

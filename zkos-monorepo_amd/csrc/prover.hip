@@ -36,6 +36,7 @@ struct shp_pk {
     // host copies
     std::vector<G1Affine> fixed_comm, sigma_comm;
     uint8_t vk_digest[32];
+    std::vector<uint8_t> plan_bytes;               // the circuit plan the key was generated from (shp_pk_save)
     Fr omega, omega_inv, delta, zeta;
     std::vector<Fr> delta_pow;
     std::vector<void*> owned;
@@ -68,11 +69,15 @@ static void launch_prog(hipStream_t st, const ProgArgs& a, uint32_t size) {
     hipLaunchKernelGGL(prog_fold_kernel, dim3(size / PROG_THREADS), dim3(PROG_THREADS), lds, st, a);
 }
 
-static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, size_t len, shp_pk** out) {
+// stored_comm: commitments read from a saved key (fixed then sigma); nullptr = compute them (MSMs)
+static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, size_t len, shp_pk** out,
+                        const std::vector<G1Affine>* stored_comm = nullptr) {
     SHP_REQUIRE(ctx && srs && plan_bytes && out, SHP_ERR_INVALID_ARG, "keygen: null argument");
+    SHP_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<shp_pk> pk(new shp_pk);
     pk->ctx = ctx;
     pk->srs = srs;
+    pk->plan_bytes.assign(plan_bytes, plan_bytes + len);
     PlanData& P = pk->plan;
     P.parse(plan_bytes, len);
     SHP_REQUIRE(P.k == srs->k, SHP_ERR_INVALID_ARG, "keygen: plan k differs from the SRS k");
@@ -166,8 +171,14 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     // commitments to the fixed and sigma columns (Lagrange basis)
     pk->fixed_comm.resize(F);
     pk->sigma_comm.resize(PC);
-    if (F) msm_run(srs->msm_gl, pk->fixed_vals, n, n, F, pk->fixed_comm.data(), st);
-    msm_run(srs->msm_gl, pk->sigma_vals, n, n, PC, pk->sigma_comm.data(), st);
+    if (stored_comm) {
+        SHP_REQUIRE(stored_comm->size() == (size_t)F + PC, SHP_ERR_FORMAT, "pk_load: commitment count differs from the plan");
+        std::copy(stored_comm->begin(), stored_comm->begin() + F, pk->fixed_comm.begin());
+        std::copy(stored_comm->begin() + F, stored_comm->end(), pk->sigma_comm.begin());
+    } else {
+        if (F) msm_run(srs->msm_gl, pk->fixed_vals, n, n, F, pk->fixed_comm.data(), st);
+        msm_run(srs->msm_gl, pk->sigma_vals, n, n, PC, pk->sigma_comm.data(), st);
+    }
     SHP_HIP(hipStreamSynchronize(st));
     // vk digest: keccak("shielder-hip-vk-v1" | keccak(plan) | commitments) mod r
     std::vector<uint8_t> body;
@@ -818,6 +829,65 @@ extern "C" {
 
 int32_t shp_keygen(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan, size_t plan_len, shp_pk** out) {
     return guarded([&] { keygen_impl(ctx, srs, plan, plan_len, out); });
+}
+
+// ---- marshall_pk / unmarshall_pk (/root/reference/crates/shielder_bindings/build.rs:24-32,
+// src/circuits/mod.rs:38-46).  Everything in the key except the commitments is a cheap, deterministic
+// GPU function of (plan, SRS) -- keygen without the MSMs is a few NTTs -- so the saved key is the
+// plan plus the verifying-key material, not tens of MB of polynomials; loading rebuilds the device
+// resident tables in milliseconds (the TEE decodes its pk.bin on every request, server.rs:170-173).
+//   "SHPK0001" | u32 k | u32 plan_len | plan | u32 F | u32 PC | F+PC x 64 B commitments | 32 B vk digest
+static const char PK_MAGIC[8] = {'S', 'H', 'P', 'K', '0', '0', '0', '1'};
+
+int32_t shp_pk_save(const shp_pk* pk, uint8_t* out, size_t out_cap, size_t* out_len) {
+    return guarded([&] {
+        SHP_REQUIRE(pk && out_len, SHP_ERR_INVALID_ARG, "pk_save: null argument");
+        const uint32_t F = (uint32_t)pk->fixed_comm.size(), PC = (uint32_t)pk->sigma_comm.size();
+        const size_t total = 8 + 4 + 4 + pk->plan_bytes.size() + 4 + 4 + (size_t)(F + PC) * sizeof(G1Affine) + 32;
+        *out_len = total;
+        if (!out) return;
+        SHP_REQUIRE(out_cap >= total, SHP_ERR_INVALID_ARG, "pk_save: buffer too small");
+        uint8_t* p = out;
+        auto put = [&](const void* src, size_t n) { memcpy(p, src, n); p += n; };
+        const uint32_t k = pk->plan.k, pl = (uint32_t)pk->plan_bytes.size();
+        put(PK_MAGIC, 8); put(&k, 4); put(&pl, 4); put(pk->plan_bytes.data(), pl); put(&F, 4); put(&PC, 4);
+        put(pk->fixed_comm.data(), (size_t)F * sizeof(G1Affine));
+        put(pk->sigma_comm.data(), (size_t)PC * sizeof(G1Affine));
+        put(pk->vk_digest, 32);
+    });
+}
+
+int32_t shp_pk_load(shp_ctx* ctx, shp_srs* srs, const uint8_t* bytes, size_t len, shp_pk** out) {
+    return guarded([&] {
+        SHP_REQUIRE(ctx && srs && bytes && out, SHP_ERR_INVALID_ARG, "pk_load: null argument");
+        const uint8_t* p = bytes;
+        const uint8_t* end = bytes + len;
+        auto need = [&](size_t n) { SHP_REQUIRE((size_t)(end - p) >= n, SHP_ERR_FORMAT, "pk_load: truncated key"); };
+        need(16);
+        SHP_REQUIRE(memcmp(p, PK_MAGIC, 8) == 0, SHP_ERR_FORMAT, "pk_load: bad magic / version");
+        uint32_t k, pl, F, PC;
+        memcpy(&k, p + 8, 4); memcpy(&pl, p + 12, 4);
+        p += 16;
+        need(pl);
+        const uint8_t* plan = p;
+        p += pl;
+        need(8);
+        memcpy(&F, p, 4); memcpy(&PC, p + 4, 4);
+        p += 8;
+        SHP_REQUIRE(F <= 4096 && PC <= MAX_PERM_COLS, SHP_ERR_FORMAT, "pk_load: implausible column counts");
+        need((size_t)(F + PC) * sizeof(G1Affine) + 32);
+        std::vector<G1Affine> comm(F + PC);
+        memcpy(comm.data(), p, comm.size() * sizeof(G1Affine));
+        p += comm.size() * sizeof(G1Affine);
+        SHP_REQUIRE(p + 32 == end, SHP_ERR_FORMAT, "pk_load: trailing bytes");
+        shp_pk* pk = nullptr;
+        keygen_impl(ctx, srs, plan, pl, &pk, &comm);
+        std::unique_ptr<shp_pk> guard(pk);
+        SHP_REQUIRE(pk->plan.k == k, SHP_ERR_FORMAT, "pk_load: k differs from the plan");
+        // the digest binds plan and commitments: a key whose parts were altered does not load
+        SHP_REQUIRE(memcmp(pk->vk_digest, p, 32) == 0, SHP_ERR_FORMAT, "pk_load: verifying-key digest mismatch");
+        *out = guard.release();
+    });
 }
 
 int32_t shp_pk_destroy(shp_pk* pk) {
