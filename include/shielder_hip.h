@@ -122,6 +122,18 @@ int32_t shp_poseidon2_t8(shp_ctx* ctx, const void* d_in, size_t n_hashes, uint32
 /* raw permutation on n_states x 8 Fr, in place */
 int32_t shp_poseidon2_t8_permute(shp_ctx* ctx, void* d_states, size_t n_states, void* stream);
 
+/* ---- arity-7 Poseidon2 Merkle tree: the witness side of the path --------------------------
+ * The tree of /root/reference/contracts/MerkleTree.sol:17-18,121-148 (ARITY 7, Poseidon2 hash of the 7
+ * children, unset slots read as 0) over `n_leaves` notes, all levels computed on the GPU, and
+ * getMerklePath (MerkleTree.sol:95-118; layout consumed by
+ * /root/reference/crates/shielder-contract/src/merkle_path.rs:17-36 and WithdrawCircuit::prove's `path`):
+ * per query height*7 ordered siblings-with-ancestor, then the root -- (7*height+1) x 32 bytes, canonical LE. */
+typedef struct shp_merkle shp_merkle;
+int32_t shp_merkle_build(shp_ctx* ctx, const void* d_leaves, size_t n_leaves, uint32_t height, shp_merkle** out);
+int32_t shp_merkle_destroy(shp_merkle* t);
+int32_t shp_merkle_root(const shp_merkle* t, uint8_t root_le32[32]);
+int32_t shp_merkle_paths(shp_merkle* t, const uint64_t* leaf_indices, size_t n_queries, uint8_t* paths_le32);
+
 /* ---- SRS ("Params") --------------------------------------------------------------- */
 /* powers_of_tau::read(.., PerpetualPowersOfTau): parses the snarkjs .ptau bytes, derives
  * g_lagrange on the GPU (group FFT), uploads both tables and builds both MSM plans. */

@@ -208,3 +208,33 @@ def test_msm_2_20_matches_oracle(shp, oracle, gpu_ctx):
     assert nbytes == 96 * n and adds > 0
     m.close()
     del torch
+
+
+def test_merkle_tree_matches_contract_semantics(shp, oracle, gpu_ctx):
+    """contracts/MerkleTree.sol through the GPU: levels = Poseidon2 of 7 children (unset = 0), getMerklePath layout
+    (siblings-with-ancestor per level, then root), against the oracle's hash"""
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    for n_leaves, height in ((1, 2), (100, 4), (343, 3)):
+        rnd = random.Random(n_leaves)
+        leaves = [rnd.randrange(R) for _ in range(n_leaves)]
+        t = shp.MerkleTree(gpu_ctx, shp.to_device(oracle.fr_array(leaves)), n_leaves, height)
+        levels = [leaves]
+        for _ in range(height):
+            cur = levels[-1]
+            levels.append([H((cur[7 * j: 7 * j + 7] + [0] * 7)[:7]) for j in range((len(cur) + 6) // 7)])
+        assert len(levels[-1]) == 1 and t.root() == levels[-1][0]
+        qs = sorted({0, n_leaves - 1, n_leaves // 2, min(7, n_leaves - 1)})
+        for (path, root), q in zip(t.paths(qs), qs):
+            assert root == levels[-1][0]
+            node = q
+            for l in range(height):
+                want = (levels[l][(node // 7) * 7: (node // 7) * 7 + 7] + [0] * 7)[:7]
+                assert path[l] == want and path[l][node % 7] == levels[l][node]
+                node //= 7
+            # the relation the withdraw circuit proves: each level's hash sits in the next level
+            for l in range(height - 1):
+                assert H(path[l]) in path[l + 1]
+            assert H(path[height - 1]) == root
+        with pytest.raises(shp.ShpError):
+            t.paths([n_leaves])
+        t.close()

@@ -195,3 +195,39 @@ def test_pk_save_load_roundtrip(shp, oracle, gpu_ctx):
     with pytest.raises(shp.ShpError):
         shp.ProvingKey.load(gpu_ctx, params, blob[:-5])
     a.close(); b.close(); pk2.close(); pk.close(); params.close()
+
+
+def test_serve_end_to_end(shp, oracle, gpu_ctx):
+    """TEE wire protocol (serve.py) over TCP on top of the native proving pool: the proof that comes back in
+    `EncryptedProof` verifies and its pub_inputs JSON are the circuit's 8 public inputs in order"""
+    import asyncio, base64, json
+    S = importlib.import_module("zkos-monorepo_amd.serve")
+    PL, C, plan, lay, osrs, opk, params, pk = setup(shp, oracle, gpu_ctx, True)
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    wit = C.withdraw_witness_inputs(lay, H, random.Random(21), 2**31 + 1, 2**20 + 2)
+    le = lambda x: list(int(x).to_bytes(32, "little"))
+    h = lay.height
+    inputs = {"id": le(wit[lay.ID]), "nullifier_old": le(wit[lay.NULLIFIER_OLD]), "account_balance_old": le(wit[lay.BALANCE_OLD]),
+              "token_address": le(wit[lay.TOKEN]), "path": [b for x in wit[4:4 + 7 * h] for b in le(x)], "value": le(wit[lay.VALUE]),
+              "nullifier_new": le(wit[lay.NULLIFIER_NEW]), "commitment": le(wit[lay.COMMITMENT]), "mac_salt": le(wit[lay.MAC_SALT])}
+    payload = {"circuit_type": "Withdraw", "user_public_key": [], "circuit_inputs": list(json.dumps(inputs).encode())}
+    req = {"GenerateProof": {"payload": list(json.dumps(payload).encode())}}
+    pool = shp.Pool(pk, 2)
+
+    async def run():
+        srv = await S.Server(S.PoolBackend(pool, h)).serve(port=0)
+        port = srv.sockets[0].getsockname()[1]
+        async with srv:
+            assert await S.request("127.0.0.1", port, "Ping") == "Pong"
+            return await asyncio.gather(*[S.request("127.0.0.1", port, req) for _ in range(3)])
+
+    resps = asyncio.run(run())
+    _, oinst = PL.synthesize(plan, wit)
+    for r in resps:
+        proof = base64.b64decode(r["EncryptedProof"]["proof"])
+        pub = json.loads(base64.b64decode(r["EncryptedProof"]["pub_inputs"]))
+        inst = [int.from_bytes(bytes(pub[f]), "little") for f in S.WITHDRAW_PUB_FIELDS]
+        assert inst == list(oinst)
+        assert PL.verify(opk, proof, inst, tau=TAU)
+    assert len({r["EncryptedProof"]["proof"] for r in resps}) == 3       # fresh randomness per request
+    pool.close(); pk.close(); params.close()

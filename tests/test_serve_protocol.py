@@ -1,0 +1,101 @@
+"""CPU: the TEE wire protocol mirror (zkos-monorepo_amd/serve.py) against the reference's message shapes
+(tee/crates/shielder-prover-common/src/protocol.rs, tee/crates/shielder-prover-tee/src/circuits/withdraw.rs),
+with a fake backend -- no GPU.  The GPU end-to-end is tests/test_gpu_prover.py::test_serve_end_to_end."""
+import asyncio
+import base64
+import importlib
+import json
+import struct
+
+import pytest
+
+S = importlib.import_module("zkos-monorepo_amd.serve")
+R = S.R_MOD
+
+
+def le(x):
+    return list(int(x).to_bytes(32, "little"))
+
+
+def make_inputs(height, bump=0):
+    vals = {"id": 5 + bump, "nullifier_old": 6, "account_balance_old": 10**18, "token_address": 0xABCD, "value": 10**17,
+            "nullifier_new": 8, "commitment": 9, "mac_salt": 10}
+    d = {k: le(v) for k, v in vals.items()}
+    d["path"] = [b for i in range(7 * height) for b in le(100 + i)]
+    return d
+
+
+def make_request(inputs, ctype="Withdraw"):
+    payload = {"circuit_type": ctype, "user_public_key": [1, 2, 3], "circuit_inputs": list(json.dumps(inputs).encode())}
+    return {"GenerateProof": {"payload": list(json.dumps(payload).encode())}}
+
+
+class FakeBackend:
+    n_height = 2
+
+    def __init__(self):
+        self.calls = []
+
+    def prove(self, wit, seed):
+        self.calls.append((wit, seed))
+        return b"PROOF" + bytes([len(self.calls)]), list(range(1, 9))
+
+
+def test_witness_vector_order_and_validation():
+    h = 2
+    wit = S.withdraw_witness_bytes(make_inputs(h), h)
+    ints = [int.from_bytes(wit[i:i + 32], "little") for i in range(0, len(wit), 32)]
+    # argument order of WithdrawCircuit::prove: id, nullifier_old, balance, token, path..., value, nullifier_new, commitment, mac_salt
+    assert ints == [5, 6, 10**18, 0xABCD] + [100 + i for i in range(14)] + [10**17, 8, 9, 10]
+    bad = make_inputs(h); bad["id"] = le(0)[:-1]
+    with pytest.raises(S.ProtocolError):
+        S.withdraw_witness_bytes(bad, h)
+    bad = make_inputs(h); bad["value"] = list(R.to_bytes(32, "little"))        # vec_to_f panics on non-canonical input
+    with pytest.raises(S.ProtocolError):
+        S.withdraw_witness_bytes(bad, h)
+    bad = make_inputs(h); del bad["mac_salt"]
+    with pytest.raises(S.ProtocolError):
+        S.withdraw_witness_bytes(bad, h)
+    bad = make_inputs(h); bad["path"] = bad["path"][:-32]
+    with pytest.raises(S.ProtocolError):
+        S.withdraw_witness_bytes(bad, h)
+
+
+def test_pub_inputs_json_shape():
+    out = json.loads(S.withdraw_pub_inputs_json([1, 2, 3, 4, 5, 6, 7, R - 1]))
+    assert list(out) == ["merkle_root", "h_nullifier_old", "h_note_new", "withdrawal_value", "token_address", "commitment",
+                         "mac_salt", "mac_commitment"]
+    assert out["merkle_root"] == le(1) and out["mac_commitment"] == le(R - 1)
+
+
+def test_server_round_trips_over_tcp():
+    be = FakeBackend()
+
+    async def run():
+        server = S.Server(be, seed_source=lambda n: bytes([7]) * n)
+        srv = await server.serve(port=0)
+        port = srv.sockets[0].getsockname()[1]
+        async with srv:
+            assert await S.request("127.0.0.1", port, "Ping") == "Pong"
+            pk = await S.request("127.0.0.1", port, "TeePublicKey")
+            assert set(pk["TeePublicKey"]) == {"public_key", "attestation_document"}
+            # two requests on ONE connection, frames are 4-byte big-endian length + JSON
+            reader, writer = await asyncio.open_connection("127.0.0.1", port)
+            for bump in (0, 1):
+                body = json.dumps(make_request(make_inputs(2, bump))).encode()
+                writer.write(struct.pack(">I", len(body)) + body)
+                await writer.drain()
+                (n,) = struct.unpack(">I", await reader.readexactly(4))
+                resp = json.loads(await reader.readexactly(n))
+                ep = resp["EncryptedProof"]
+                assert base64.b64decode(ep["proof"]) == b"PROOF" + bytes([bump + 1])
+                assert json.loads(base64.b64decode(ep["pub_inputs"]))["h_nullifier_old"] == le(2)
+            writer.close()
+            # protocol errors drop the connection (the reference returns Err from handle_request)
+            for bad in ({"GenerateProof": {"payload": list(b"not json")}}, make_request(make_inputs(2), "Deposit"), "Nope"):
+                with pytest.raises(asyncio.IncompleteReadError):
+                    await S.request("127.0.0.1", port, bad)
+        return server.served
+
+    assert asyncio.run(run()) == 2
+    assert len(be.calls) == 2 and be.calls[0][1] == bytes([7]) * 32 and len(be.calls[0][0]) == 32 * (8 + 14)

@@ -355,6 +355,38 @@ class Prover:
             self.h = C.c_void_p()
 
 
+class MerkleTree:
+    """Arity-7 Poseidon2 Merkle tree on the GPU (contracts/MerkleTree.sol): build over leaves resident in
+    HBM, then getMerklePath for batches of leaves."""
+
+    def __init__(self, ctx: Context, t_leaves, n_leaves: int, height: int):
+        self.height = height
+        self.h = C.c_void_p()
+        _check(lib().shp_merkle_build(ctx.h, _vp(t_leaves.data_ptr()), C.c_size_t(n_leaves), C.c_uint32(height), C.byref(self.h)))
+
+    def root(self) -> int:
+        out = C.create_string_buffer(32)
+        _check(lib().shp_merkle_root(self.h, out))
+        return int.from_bytes(out.raw, "little")
+
+    def paths(self, indices):
+        """-> list of (path[height][7] ints, root) in the reference's reorganize_merkle_path shape"""
+        idx = (C.c_uint64 * len(indices))(*indices)
+        per = 7 * self.height + 1
+        out = C.create_string_buffer(32 * per * len(indices))
+        _check(lib().shp_merkle_paths(self.h, idx, C.c_size_t(len(indices)), out))
+        res = []
+        for q in range(len(indices)):
+            flat = [int.from_bytes(out.raw[32 * (q * per + e): 32 * (q * per + e + 1)], "little") for e in range(per)]
+            res.append(([flat[7 * l: 7 * l + 7] for l in range(self.height)], flat[-1]))
+        return res
+
+    def close(self):
+        if self.h:
+            lib().shp_merkle_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 def encode_calldata(proof: bytes, instances) -> bytes:
     """halo2_verifier::encode_calldata: calldata of Halo2Verifier.verifyProof(bytes,uint256[])
     (/root/reference/crates/halo2-verifier/src/lib/verifier_contract.rs:13-20)"""

@@ -1,0 +1,193 @@
+"""Prover server speaking the reference's TEE wire protocol, without the enclave-only parts.
+
+Mirrors (field names, enum tagging, framing):
+  Request / Response / Payload / CircuitType   /root/reference/tee/crates/shielder-prover-common/src/protocol.rs:14-68
+  framing: 4-byte big-endian length + one JSON value per frame (tokio LengthDelimitedCodec defaults)
+                                                /root/reference/tee/crates/shielder-prover-common/src/vsock.rs:69-102
+  WithdrawProveInputsBytes / WithdrawPubInputsBytes (byte vectors as JSON number arrays)
+                                                /root/reference/tee/crates/shielder-prover-tee/src/circuits/withdraw.rs:12-23, 64-76
+  request flow (decode payload -> pub inputs -> prove -> respond)
+                                                /root/reference/tee/crates/shielder-prover-tee/src/server.rs:75-90, 128-195
+Differences, all deliberate (out of scope: AWS Nitro specifics):
+  * transport is TCP on localhost instead of vsock; * the payload is NOT ECIES-encrypted and the
+  `EncryptedProof` fields carry the plain proof / public-input JSON; * `TeePublicKey` answers with
+  an empty key and attestation document; * the proving key is resident in HBM and proofs go
+  through the native proving pool (shp_pool) instead of being re-decoded per request.
+The prover backend is any object with `n_height`, `prove(witness_bytes, seed) -> (proof, [ints])`.
+"""
+import asyncio
+import base64
+import json
+import os
+import struct
+
+R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+CIRCUIT_TYPES = ("NewAccount", "Deposit", "Withdraw")            # protocol.rs:62-68
+WITHDRAW_INPUT_FIELDS = ("id", "nullifier_old", "account_balance_old", "token_address", "path", "value",
+                         "nullifier_new", "commitment", "mac_salt")   # withdraw.rs:64-76
+WITHDRAW_PUB_FIELDS = ("merkle_root", "h_nullifier_old", "h_note_new", "withdrawal_value", "token_address",
+                       "commitment", "mac_salt", "mac_commitment")    # withdraw.rs:12-23
+
+
+class ProtocolError(Exception):
+    """VsockError::Protocol"""
+
+
+# ---- framing --------------------------------------------------------------------------------
+def encode_frame(obj) -> bytes:
+    body = json.dumps(obj, separators=(",", ":")).encode()
+    return struct.pack(">I", len(body)) + body
+
+
+async def read_frame(reader: asyncio.StreamReader):
+    hdr = await reader.readexactly(4)
+    (n,) = struct.unpack(">I", hdr)
+    if n > 8 * 1024 * 1024:                                     # LengthDelimitedCodec max_frame_length default
+        raise ProtocolError("frame too large")
+    return json.loads(await reader.readexactly(n))
+
+
+# ---- message mapping ------------------------------------------------------------------------
+def _bytes_field(v, name, length=None):
+    if not isinstance(v, list) or any(not isinstance(b, int) or b < 0 or b > 255 for b in v):
+        raise ProtocolError(f"{name}: expected a byte array")
+    if length is not None and len(v) != length:
+        raise ProtocolError(f"{name}: expected {length} bytes, got {len(v)}")
+    return bytes(v)
+
+
+def withdraw_witness_bytes(inputs: dict, height: int) -> bytes:
+    """WithdrawProveInputsBytes -> the prover's witness-input vector (argument order of
+    WithdrawCircuit::prove, crates/shielder_bindings/src/circuits/withdraw.rs:88-114): canonical
+    32-byte little-endian field elements; path = height x 7 x 32 bytes row-major (utils.rs:36-60)."""
+    missing = [f for f in WITHDRAW_INPUT_FIELDS if f not in inputs]
+    if missing:
+        raise ProtocolError(f"circuit_inputs: missing fields {missing}")
+    parts = []
+    for f in WITHDRAW_INPUT_FIELDS:
+        b = _bytes_field(inputs[f], f, 32 * 7 * height if f == "path" else 32)
+        for off in range(0, len(b), 32):
+            if int.from_bytes(b[off:off + 32], "little") >= R_MOD:
+                raise ProtocolError(f"{f}: not a canonical field element")   # vec_to_f panics there (utils.rs:33)
+        parts.append(b)
+    return b"".join(parts)
+
+
+def withdraw_pub_inputs_json(instances) -> bytes:
+    """WithdrawPubInputsBytes as serde_json::to_vec writes it (server.rs:192)"""
+    assert len(instances) == len(WITHDRAW_PUB_FIELDS)
+    return json.dumps({f: list(int(x).to_bytes(32, "little")) for f, x in zip(WITHDRAW_PUB_FIELDS, instances)},
+                      separators=(",", ":")).encode()
+
+
+def decode_payload(payload_bytes: bytes):
+    """Payload {circuit_type, user_public_key, circuit_inputs} (protocol.rs:14-20); circuit_inputs is
+    UTF-8 JSON of the circuit's *ProveInputsBytes"""
+    try:
+        p = json.loads(payload_bytes.decode("utf-8"))
+    except (UnicodeDecodeError, ValueError) as e:
+        raise ProtocolError(f"payload: {e}")
+    if not isinstance(p, dict) or p.get("circuit_type") not in CIRCUIT_TYPES:
+        raise ProtocolError("payload: bad circuit_type")
+    _bytes_field(p.get("user_public_key"), "user_public_key")
+    ci = _bytes_field(p.get("circuit_inputs"), "circuit_inputs")
+    try:
+        inputs = json.loads(ci.decode("utf-8"))
+    except (UnicodeDecodeError, ValueError) as e:
+        raise ProtocolError(f"circuit_inputs: {e}")
+    return p["circuit_type"], inputs
+
+
+class Server:
+    def __init__(self, backend, seed_source=os.urandom):
+        self.backend = backend
+        self.seed_source = seed_source          # the reference uses rand::thread_rng() (withdraw.rs:112)
+        self.served = 0
+
+    async def handle_request(self, req, loop):
+        if req == "Ping":
+            return "Pong"
+        if req == "TeePublicKey":
+            return {"TeePublicKey": {"public_key": "", "attestation_document": ""}}
+        if isinstance(req, dict) and "GenerateProof" in req:
+            payload = _bytes_field(req["GenerateProof"].get("payload"), "payload")
+            ctype, inputs = decode_payload(payload)
+            if ctype != "Withdraw":
+                raise ProtocolError(f"circuit {ctype}: no proving key loaded")
+            wit = withdraw_witness_bytes(inputs, self.backend.n_height)
+            proof, instances = await loop.run_in_executor(None, self.backend.prove, wit, self.seed_source(32))
+            self.served += 1
+            return {"EncryptedProof": {"proof": base64.b64encode(proof).decode(),
+                                       "pub_inputs": base64.b64encode(withdraw_pub_inputs_json(instances)).decode()}}
+        raise ProtocolError("unknown request")
+
+    async def handle_client(self, reader, writer):
+        loop = asyncio.get_running_loop()
+        try:
+            while True:
+                try:
+                    req = await read_frame(reader)
+                except asyncio.IncompleteReadError:
+                    break
+                writer.write(encode_frame(await self.handle_request(req, loop)))
+                await writer.drain()
+        except (ProtocolError, ValueError) as e:      # the reference drops the connection on a protocol error
+            print(f"[serve] protocol error: {e}", flush=True)
+        finally:
+            writer.close()
+
+    async def serve(self, host="127.0.0.1", port=5000):      # VSOCK_PORT = 5000 (protocol.rs:8)
+        srv = await asyncio.start_server(self.handle_client, host, port)
+        return srv
+
+
+class PoolBackend:
+    """proofs through the native proving pool (shp_pool): N lanes of one HBM-resident key"""
+
+    def __init__(self, pool, height):
+        self.pool, self.n_height = pool, height
+
+    def prove(self, wit: bytes, seed: bytes):
+        return self.pool.wait(self.pool.submit(wit, seed))
+
+
+async def request(host, port, req):
+    """ProverClient::request (vsock.rs:37-40)"""
+    reader, writer = await asyncio.open_connection(host, port)
+    writer.write(encode_frame(req))
+    await writer.drain()
+    try:
+        return await read_frame(reader)
+    finally:
+        writer.close()
+
+
+def main():
+    import argparse
+    import importlib
+    ap = argparse.ArgumentParser(description="Shielder prover server on one MI355X (TEE wire protocol over TCP)")
+    ap.add_argument("--port", type=int, default=5000)
+    ap.add_argument("--lanes", type=int, default=16)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--tau", type=lambda s: int(s, 0), default=0x2B6F1C0A94D3E5F7081A2B3C4D5E6F7013,
+                    help="trapdoor of the synthetic k=13 SRS (the real ppot_0080_13.ptau is not shipped); --ptau overrides")
+    ap.add_argument("--ptau", help="path of a snarkjs .ptau file with 2^13 powers")
+    a = ap.parse_args()
+    shp = importlib.import_module(__package__ or "zkos-monorepo_amd")
+    circuits = importlib.import_module((__package__ or "zkos-monorepo_amd") + ".circuits")
+    ctx = shp.Context(a.device)
+    plan, lay = circuits.build_withdraw_plan()
+    params = shp.Params.read_ptau(ctx, open(a.ptau, "rb").read()) if a.ptau else shp.Params.synthetic(ctx, 13, a.tau)
+    pk = shp.ProvingKey(ctx, params, plan)
+    pool = shp.Pool(pk, a.lanes)
+
+    async def run():
+        srv = await Server(PoolBackend(pool, lay.height)).serve(port=a.port)
+        print(f"[serve] listening on 127.0.0.1:{a.port}, {a.lanes} lanes", flush=True)
+        async with srv:
+            await srv.serve_forever()
+    asyncio.run(run())
+
+
+if __name__ == "__main__":
+    main()
