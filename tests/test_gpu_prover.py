@@ -155,7 +155,7 @@ def test_config1_real_srs_k11_proof_and_pairing(shp, oracle, gpu_ctx):
     PL = importlib.import_module("oracle.plonk")
     C = importlib.import_module("zkos-monorepo_amd.circuits")
     raw = open(golden_path("ppot_0080_11_raw"), "rb").read()
-    plan_bytes, lay = C.build_withdraw_plan(k=11, height=3, range_bits=8, range_chunks=10)
+    plan_bytes, lay = C.build_deposit_plan(k=11, height=3, range_bits=8, range_chunks=10)   # config 1 names the deposit circuit
     params = shp.Params.read_raw(gpu_ctx, raw)
     pk = shp.ProvingKey(gpu_ctx, params, plan_bytes)
     osrs = oracle.srs_from_halo2_raw(raw)
@@ -231,3 +231,22 @@ def test_serve_end_to_end(shp, oracle, gpu_ctx):
         assert PL.verify(opk, proof, inst, tau=TAU)
     assert len({r["EncryptedProof"]["proof"] for r in resps}) == 3       # fresh randomness per request
     pool.close(); pk.close(); params.close()
+
+
+def test_deposit_shaped_plan_proof_bytes(shp, oracle, gpu_ctx):
+    """the Deposit-shaped plan (DepositProverKnowledge argument / instance order) through the HIP prover"""
+    from oracle import plonk as PL
+    C = importlib.import_module("zkos-monorepo_amd.circuits")
+    plan_bytes, lay = C.build_deposit_plan(k=9, height=1, range_bits=4, range_chunks=8)
+    osrs = oracle.srs_synthetic(9, TAU)
+    opk = PL.keygen(PL.Plan(plan_bytes), osrs)
+    params = shp.Params.from_parts(gpu_ctx, 9, osrs.g, osrs.g_lagrange)
+    pk = shp.ProvingKey(gpu_ctx, params, plan_bytes)
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    wit = C.withdraw_witness_inputs(lay, H, random.Random(4), 2**31 + 5, 2**20 + 3)
+    pr = shp.Prover(pk)
+    proof, inst = pr.prove(wit, bytes([3]) * 32)
+    assert (proof, inst) == PL.prove(opk, osrs, wit, bytes([3]) * 32)
+    assert inst[3:6] == [wit[lay.VALUE], wit[lay.COMMITMENT], wit[lay.TOKEN]]
+    assert PL.verify(opk, proof, inst, tau=TAU)
+    pr.close(); pk.close(); params.close()

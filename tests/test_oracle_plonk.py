@@ -39,7 +39,7 @@ def test_config1_plumbing_proof_real_srs(oracle):
     the real pairing; tampered proof / wrong public input rejected"""
     from oracle import plonk as PL
     C = importlib.import_module("zkos-monorepo_amd.circuits")
-    plan_bytes, lay = C.build_withdraw_plan(k=11, height=3, range_bits=8, range_chunks=10)
+    plan_bytes, lay = C.build_deposit_plan(k=11, height=3, range_bits=8, range_chunks=10)   # config 1 names the deposit circuit
     plan = PL.Plan(plan_bytes)
     srs = oracle.srs_from_halo2_raw(open(golden_path("ppot_0080_11_raw"), "rb").read())
     opk = PL.keygen(plan, srs)
@@ -48,6 +48,10 @@ def test_config1_plumbing_proof_real_srs(oracle):
     proof, inst = PL.prove(opk, srs, wit, bytes(range(32)))
     assert len(proof) == PL.proof_layout(plan)[2]
     assert len(inst) == 8
+    # DepositInstance order: ..., DepositValue, Commitment, TokenAddress, MacSalt, ... (deposit.rs:17-27)
+    assert inst[3] == wit[lay.VALUE] and inst[4] == wit[lay.COMMITMENT] and inst[5] == wit[lay.TOKEN] and inst[6] == wit[lay.MAC_SALT]
+    assert inst[1] == H([wit[lay.NULLIFIER_OLD]]) and inst[7] == H([wit[lay.MAC_SALT], wit[lay.ID]])
+    assert inst[2] == H([wit[lay.ID], wit[lay.NULLIFIER_NEW], wit[lay.BALANCE_OLD] + wit[lay.VALUE], wit[lay.TOKEN]])
     assert PL.verify(opk, proof, inst, g2=srs.g2, s_g2=srs.s_g2)
     bad = bytearray(proof); bad[100] ^= 1
     assert not PL.verify(opk, bytes(bad), inst, g2=srs.g2, s_g2=srs.s_g2)

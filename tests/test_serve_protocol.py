@@ -69,10 +69,10 @@ def test_pub_inputs_json_shape():
 
 
 def test_server_round_trips_over_tcp():
-    be = FakeBackend()
+    be, dep = FakeBackend(), FakeBackend()
 
     async def run():
-        server = S.Server(be, seed_source=lambda n: bytes([7]) * n)
+        server = S.Server({"Withdraw": be, "Deposit": dep}, seed_source=lambda n: bytes([7]) * n)
         srv = await server.serve(port=0)
         port = srv.sockets[0].getsockname()[1]
         async with srv:
@@ -91,11 +91,17 @@ def test_server_round_trips_over_tcp():
                 assert base64.b64decode(ep["proof"]) == b"PROOF" + bytes([bump + 1])
                 assert json.loads(base64.b64decode(ep["pub_inputs"]))["h_nullifier_old"] == le(2)
             writer.close()
+            # the Deposit circuit has its own argument order (value, commitment, nullifier_new) and field names
+            r = await S.request("127.0.0.1", port, make_request(make_inputs(2), "Deposit"))
+            assert set(json.loads(base64.b64decode(r["EncryptedProof"]["pub_inputs"]))) == set(S.DEPOSIT_PUB_FIELDS)
             # protocol errors drop the connection (the reference returns Err from handle_request)
-            for bad in ({"GenerateProof": {"payload": list(b"not json")}}, make_request(make_inputs(2), "Deposit"), "Nope"):
+            for bad in ({"GenerateProof": {"payload": list(b"not json")}}, make_request(make_inputs(2), "NewAccount"), "Nope"):
                 with pytest.raises(asyncio.IncompleteReadError):
                     await S.request("127.0.0.1", port, bad)
         return server.served
 
-    assert asyncio.run(run()) == 2
+    assert asyncio.run(run()) == 3
+    dw = dep.calls[0][0]
+    tail = [int.from_bytes(dw[i:i + 32], "little") for i in range(32 * 18, 32 * 22, 32)]
+    assert tail == [10**17, 9, 8, 10]                      # value, commitment, nullifier_new, mac_salt
     assert len(be.calls) == 2 and be.calls[0][1] == bytes([7]) * 32 and len(be.calls[0][0]) == 32 * (8 + 14)

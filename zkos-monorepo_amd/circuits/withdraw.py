@@ -29,19 +29,27 @@ class WithdrawLayout:
     INSTANCES = ["MerkleRoot", "HashedOldNullifier", "HashedNewNote", "WithdrawalValue", "TokenAddress",
                  "Commitment", "MacSalt", "MacCommitment"]
 
-    def __init__(self, height):
+    def __init__(self, height, kind="withdraw"):
+        assert kind in ("withdraw", "deposit")
         self.height = height
+        self.kind = kind
         self.n_inputs = 4 + 7 * height + 4
+        if kind == "deposit":
+            # DepositInstance order (crates/shielder_bindings/src/circuits/deposit.rs:17-27,
+            # contracts/Shielder.sol:504-519)
+            self.INSTANCES = ["MerkleRoot", "HashedOldNullifier", "HashedNewNote", "DepositValue", "Commitment",
+                              "TokenAddress", "MacSalt", "MacCommitment"]
 
-    # witness input vector layout: the order of WithdrawCircuit::prove's arguments (withdraw.rs:88-114)
+    # witness input vector layout: the order of WithdrawCircuit::prove's arguments (withdraw.rs:88-114);
+    # DepositCircuit::prove swaps the tail: value, commitment, nullifier_new, mac_salt (deposit.rs:88-114)
     ID, NULLIFIER_OLD, BALANCE_OLD, TOKEN, PATH = 0, 1, 2, 3, 4
     def path(self, level, j): return 4 + 7 * level + j
     @property
     def VALUE(self): return 4 + 7 * self.height
     @property
-    def NULLIFIER_NEW(self): return 5 + 7 * self.height
+    def NULLIFIER_NEW(self): return (5 if self.kind == "withdraw" else 6) + 7 * self.height
     @property
-    def COMMITMENT(self): return 6 + 7 * self.height
+    def COMMITMENT(self): return (6 if self.kind == "withdraw" else 5) + 7 * self.height
     @property
     def MAC_SALT(self): return 7 + 7 * self.height
 
@@ -63,9 +71,15 @@ def _external(s):
     return [x[i] + w[i] for i in range(4)] + [x[i + 4] + w[i] for i in range(4)]
 
 
-def build_withdraw_plan(k=13, height=13, range_bits=12, range_chunks=10):
+def build_deposit_plan(k=13, height=13, range_bits=12, range_chunks=10):
+    """Deposit-shaped stand-in (DepositProverKnowledge, crates/shielder_bindings/src/circuits/deposit.rs:88-114):
+    the withdraw relation with balance_new = balance_old + value and the Deposit instance / argument order."""
+    return build_withdraw_plan(k, height, range_bits, range_chunks, kind="deposit")
+
+
+def build_withdraw_plan(k=13, height=13, range_bits=12, range_chunks=10, kind="withdraw"):
     b = PlanBuilder(k)
-    lay = WithdrawLayout(height)
+    lay = WithdrawLayout(height, kind)
     b.n_winputs = lay.n_inputs
     b.num_instance = 8
     s = [b.advice_column() for _ in range(8)]
@@ -214,15 +228,21 @@ def build_withdraw_plan(k=13, height=13, range_bits=12, range_chunks=10):
             b.copy(A(s[j + 1], mr), A(s[j], r_lvl))
         cur_node = node
     root = cur_node
-    # balance_new + value = balance_old
+    # add row, gate s0 + s1 = s2.  withdraw: balance_new + value = balance_old; deposit: balance_old + value = balance_new
     ar = state["row"]
     state["row"] += 1
     b.fix(q_add, ar, 1)
     b.w(W_INPUT, (s[1], ar), imm=lay.VALUE)
-    b.w(W_COPY, (s[2], ar), bal_old_cell)
-    b.copy(A(s[2], ar), A(*bal_old_cell))
-    b.w(W_SUB, (s[0], ar), (s[2], ar), (s[1], ar))
-    bal_new_cell, value_cell = (s[0], ar), (s[1], ar)
+    if kind == "withdraw":
+        b.w(W_COPY, (s[2], ar), bal_old_cell)
+        b.copy(A(s[2], ar), A(*bal_old_cell))
+        b.w(W_SUB, (s[0], ar), (s[2], ar), (s[1], ar))
+        bal_new_cell, value_cell = (s[0], ar), (s[1], ar)
+    else:
+        b.w(W_COPY, (s[0], ar), bal_old_cell)
+        b.copy(A(s[0], ar), A(*bal_old_cell))
+        b.w(W_ADD, (s[2], ar), (s[0], ar), (s[1], ar))
+        bal_new_cell, value_cell = (s[2], ar), (s[1], ar)
 
     def range_check(cell):
         r0 = state["row"]
@@ -250,8 +270,12 @@ def build_withdraw_plan(k=13, height=13, range_bits=12, range_chunks=10):
     expose(h_null, 1)
     expose(note_new, 2)
     expose(value_cell, 3)
-    expose(token_cell, 4)
-    expose(commitment_cell, 5)
+    if kind == "withdraw":
+        expose(token_cell, 4)
+        expose(commitment_cell, 5)
+    else:
+        expose(commitment_cell, 4)
+        expose(token_cell, 5)
     expose(mac_salt_cell, 6)
     expose(mac, 7)
     usable = b.n - (b.blinding_factors() + 1)
@@ -272,6 +296,7 @@ def withdraw_witness_inputs(lay, hash_fn, rnd, balance_old=10**18, value=10**17)
         sib[rnd.randrange(7)] = node
         path.append(sib)
         node = hash_fn(sib)
-    flat = [ident, n_old, balance_old, token] + [x for lv in path for x in lv] + [value, n_new, commitment, salt]
+    tail = [value, n_new, commitment, salt] if lay.kind == "withdraw" else [value, commitment, n_new, salt]
+    flat = [ident, n_old, balance_old, token] + [x for lv in path for x in lv] + tail
     assert len(flat) == lay.n_inputs
     return flat

@@ -27,6 +27,12 @@ WITHDRAW_INPUT_FIELDS = ("id", "nullifier_old", "account_balance_old", "token_ad
                          "nullifier_new", "commitment", "mac_salt")   # withdraw.rs:64-76
 WITHDRAW_PUB_FIELDS = ("merkle_root", "h_nullifier_old", "h_note_new", "withdrawal_value", "token_address",
                        "commitment", "mac_salt", "mac_commitment")    # withdraw.rs:12-23
+DEPOSIT_INPUT_FIELDS = ("id", "nullifier_old", "account_balance_old", "token_address", "path", "value",
+                        "commitment", "nullifier_new", "mac_salt")    # tee/.../circuits/deposit.rs:61-72
+DEPOSIT_PUB_FIELDS = ("merkle_root", "h_nullifier_old", "h_note_new", "value", "commitment", "token_address",
+                      "mac_salt", "mac_commitment")                   # tee/.../circuits/deposit.rs:13-22
+INPUT_FIELDS = {"Withdraw": WITHDRAW_INPUT_FIELDS, "Deposit": DEPOSIT_INPUT_FIELDS}
+PUB_FIELDS = {"Withdraw": WITHDRAW_PUB_FIELDS, "Deposit": DEPOSIT_PUB_FIELDS}
 
 
 class ProtocolError(Exception):
@@ -56,15 +62,16 @@ def _bytes_field(v, name, length=None):
     return bytes(v)
 
 
-def withdraw_witness_bytes(inputs: dict, height: int) -> bytes:
-    """WithdrawProveInputsBytes -> the prover's witness-input vector (argument order of
-    WithdrawCircuit::prove, crates/shielder_bindings/src/circuits/withdraw.rs:88-114): canonical
-    32-byte little-endian field elements; path = height x 7 x 32 bytes row-major (utils.rs:36-60)."""
-    missing = [f for f in WITHDRAW_INPUT_FIELDS if f not in inputs]
+def withdraw_witness_bytes(inputs: dict, height: int, fields=WITHDRAW_INPUT_FIELDS) -> bytes:
+    """WithdrawProveInputsBytes / DepositProveInputBytes -> the prover's witness-input vector (argument
+    order of WithdrawCircuit::prove / DepositCircuit::prove, crates/shielder_bindings/src/circuits/
+    withdraw.rs:88-114, deposit.rs:88-114): canonical 32-byte little-endian field elements;
+    path = height x 7 x 32 bytes row-major (utils.rs:36-60)."""
+    missing = [f for f in fields if f not in inputs]
     if missing:
         raise ProtocolError(f"circuit_inputs: missing fields {missing}")
     parts = []
-    for f in WITHDRAW_INPUT_FIELDS:
+    for f in fields:
         b = _bytes_field(inputs[f], f, 32 * 7 * height if f == "path" else 32)
         for off in range(0, len(b), 32):
             if int.from_bytes(b[off:off + 32], "little") >= R_MOD:
@@ -73,10 +80,10 @@ def withdraw_witness_bytes(inputs: dict, height: int) -> bytes:
     return b"".join(parts)
 
 
-def withdraw_pub_inputs_json(instances) -> bytes:
-    """WithdrawPubInputsBytes as serde_json::to_vec writes it (server.rs:192)"""
-    assert len(instances) == len(WITHDRAW_PUB_FIELDS)
-    return json.dumps({f: list(int(x).to_bytes(32, "little")) for f, x in zip(WITHDRAW_PUB_FIELDS, instances)},
+def withdraw_pub_inputs_json(instances, fields=WITHDRAW_PUB_FIELDS) -> bytes:
+    """WithdrawPubInputsBytes / DepositPubInputsBytes as serde_json::to_vec writes it (server.rs:192)"""
+    assert len(instances) == len(fields)
+    return json.dumps({f: list(int(x).to_bytes(32, "little")) for f, x in zip(fields, instances)},
                       separators=(",", ":")).encode()
 
 
@@ -100,7 +107,8 @@ def decode_payload(payload_bytes: bytes):
 
 class Server:
     def __init__(self, backend, seed_source=os.urandom):
-        self.backend = backend
+        """backend: one prover (serves Withdraw) or {circuit type: prover} (CircuitType, protocol.rs:62-68)"""
+        self.backends = backend if isinstance(backend, dict) else {"Withdraw": backend}
         self.seed_source = seed_source          # the reference uses rand::thread_rng() (withdraw.rs:112)
         self.served = 0
 
@@ -112,13 +120,14 @@ class Server:
         if isinstance(req, dict) and "GenerateProof" in req:
             payload = _bytes_field(req["GenerateProof"].get("payload"), "payload")
             ctype, inputs = decode_payload(payload)
-            if ctype != "Withdraw":
+            backend = self.backends.get(ctype)
+            if backend is None or ctype not in INPUT_FIELDS:
                 raise ProtocolError(f"circuit {ctype}: no proving key loaded")
-            wit = withdraw_witness_bytes(inputs, self.backend.n_height)
-            proof, instances = await loop.run_in_executor(None, self.backend.prove, wit, self.seed_source(32))
+            wit = withdraw_witness_bytes(inputs, backend.n_height, INPUT_FIELDS[ctype])
+            proof, instances = await loop.run_in_executor(None, backend.prove, wit, self.seed_source(32))
             self.served += 1
-            return {"EncryptedProof": {"proof": base64.b64encode(proof).decode(),
-                                       "pub_inputs": base64.b64encode(withdraw_pub_inputs_json(instances)).decode()}}
+            pub = withdraw_pub_inputs_json(instances, PUB_FIELDS[ctype])
+            return {"EncryptedProof": {"proof": base64.b64encode(proof).decode(), "pub_inputs": base64.b64encode(pub).decode()}}
         raise ProtocolError("unknown request")
 
     async def handle_client(self, reader, writer):
@@ -176,13 +185,14 @@ def main():
     shp = importlib.import_module(__package__ or "zkos-monorepo_amd")
     circuits = importlib.import_module((__package__ or "zkos-monorepo_amd") + ".circuits")
     ctx = shp.Context(a.device)
-    plan, lay = circuits.build_withdraw_plan()
     params = shp.Params.read_ptau(ctx, open(a.ptau, "rb").read()) if a.ptau else shp.Params.synthetic(ctx, 13, a.tau)
-    pk = shp.ProvingKey(ctx, params, plan)
-    pool = shp.Pool(pk, a.lanes)
+    backends = {}
+    for ctype, build in (("Withdraw", circuits.build_withdraw_plan), ("Deposit", circuits.build_deposit_plan)):
+        plan, lay = build()
+        backends[ctype] = PoolBackend(shp.Pool(shp.ProvingKey(ctx, params, plan), a.lanes), lay.height)
 
     async def run():
-        srv = await Server(PoolBackend(pool, lay.height)).serve(port=a.port)
+        srv = await Server(backends).serve(port=a.port)
         print(f"[serve] listening on 127.0.0.1:{a.port}, {a.lanes} lanes", flush=True)
         async with srv:
             await srv.serve_forever()
