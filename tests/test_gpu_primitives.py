@@ -238,3 +238,30 @@ def test_merkle_tree_matches_contract_semantics(shp, oracle, gpu_ctx):
         with pytest.raises(shp.ShpError):
             t.paths([n_leaves])
         t.close()
+
+
+def test_msm_direct_tree_special_cases(shp, oracle, gpu_ctx):
+    """the cooperative tree additions of the direct-table MSM: equal partial sums (doubling), opposite
+    partial sums (cancel to the identity), identities scattered among the lanes"""
+    n = 4096
+    osrs = oracle.srs_synthetic(12, 0xDEADBEEFCAFE1234567)
+    bases = osrs.g.copy()
+    bases[1::2] = bases[0::2]                      # every base twice: lanes 2i and 2i+1 hold the same point
+    m = shp.Msm(gpu_ctx, bases)
+    rnd = random.Random(5)
+    same = [0] * n
+    opp = [0] * n
+    mixed = [0] * n
+    for i in range(0, n, 2):
+        s = rnd.randrange(1, R)
+        same[i] = same[i + 1] = s                  # P + P at the first tree level
+        opp[i], opp[i + 1] = s, R - s              # P + (-P)
+        mixed[i] = s if i % 8 == 0 else 0
+        mixed[i + 1] = s if i % 16 == 0 else 0
+    cols = [same, opp, mixed, [5] * n, [R - 5 if i % 2 else 5 for i in range(n)]]
+    s_arr = oracle.fr_array([x for c in cols for x in c])
+    got = m.run(shp.to_device(s_arr), n, len(cols))
+    for i, c in enumerate(cols):
+        assert np.array_equal(got[i], oracle.msm(bases, s_arr.reshape(len(cols), n, 4)[i])), f"column {i}"
+    assert not got[1].any() and not got[4].any()   # everything cancels
+    m.close()

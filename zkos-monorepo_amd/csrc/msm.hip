@@ -386,38 +386,149 @@ __device__ __forceinline__ G1Affine load_affine(const G1Affine* p) {
 }
 
 // Sum of one XYZZ point per thread over a 256-thread workgroup; the result is valid in thread 0.
-// The tree runs through LDS in [dword][thread] order (conflict free) so that each level is
-// executed by as few WAVES as hold its live lanes (2, then 1) -- a __shfl butterfly would make all
-// four waves execute all eight levels: 26 wave-level additions instead of 9.
-__device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [32][256] */) {
+//
+// The points live in LDS in [coordinate][limb][slot] order (conflict free).  Level 256 -> 128 is one
+// ordinary addition per lane on two waves.  From 64 additions down, FOUR lanes cooperate on each
+// addition: the 14 field products of add-2008-s have a dependency depth of only four
+//   R1  u1 = x1 zz2 | s1 = y1 zzz2 | u2 = x2 zz1 | s2 = y2 zzz1
+//   R2  pp = (u2-u1)^2 | rr2 = (s2-s1)^2 | zz12 = zz1 zz2 | zzz12 = zzz1 zzz2
+//   R3  qq = u1 pp | - | zz3 = zz12 pp | ppp = (u2-u1) pp
+//   R4  x3 = rr2-ppp-2qq, t2 = rr (qq-x3) | t1 = s1 ppp | - | zzz3 = zzz12 ppp          y3 = t2 - t1
+// so a level costs four product rounds instead of fourteen, which is what bounds the latency of a
+// small MSM (a lone wave issues one instruction per ~8 cycles whatever its ILP).  Operands and
+// intermediates travel between the four lanes through LDS.  Identity operands are selected
+// around; the doubling / opposite-point cases (pp == 0) are rare and redone by lane 0 of the quad
+// with the generic g1_add.
+constexpr uint32_t COOP_POINT_WORDS = 32 * MSM_THREADS;       // [4 coords][8 limbs][256 slots]
+constexpr uint32_t COOP_SCR_WORDS = 12 * 8 * 64;              // [12 values][8 limbs][64 quads]
+constexpr uint32_t COOP_LDS_WORDS = COOP_POINT_WORDS + COOP_SCR_WORDS + 64;
+
+__device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_WORDS] */) {
     const uint32_t t = threadIdx.x;
-    auto put = [&](const G1X& p) {
-        const uint32_t* s = reinterpret_cast<const uint32_t*>(&p);
+    uint32_t* scr = sh + COOP_POINT_WORDS;
+    uint32_t* flg = scr + COOP_SCR_WORDS;                       // per quad: bit0 inf1, bit1 inf2, bit2 pp == 0
+    auto ldc = [&](uint32_t coord, uint32_t slot) {
+        Fq v;
 #pragma unroll
-        for (int i = 0; i < 32; i++) sh[i * MSM_THREADS + t] = s[i];
+        for (int i = 0; i < 8; i++) v.l[i] = sh[(coord * 8 + i) * MSM_THREADS + slot];
+        return v;
     };
-    auto get = [&](uint32_t from) {
-        G1X p;
-        uint32_t* d = reinterpret_cast<uint32_t*>(&p);
+    auto stc = [&](uint32_t coord, uint32_t slot, const Fq& v) {
 #pragma unroll
-        for (int i = 0; i < 32; i++) d[i] = sh[i * MSM_THREADS + from];
+        for (int i = 0; i < 8; i++) sh[(coord * 8 + i) * MSM_THREADS + slot] = v.l[i];
+    };
+    auto lds = [&](uint32_t val, uint32_t quad) {
+        Fq v;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v.l[i] = scr[(val * 8 + i) * 64 + quad];
+        return v;
+    };
+    auto sts = [&](uint32_t val, uint32_t quad, const Fq& v) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) scr[(val * 8 + i) * 64 + quad] = v.l[i];
+    };
+    auto put = [&](uint32_t slot, const G1X& p) { stc(0, slot, p.x); stc(1, slot, p.y); stc(2, slot, p.zz); stc(3, slot, p.zzz); };
+    auto get = [&](uint32_t slot) {
+        G1X p;
+        p.x = ldc(0, slot); p.y = ldc(1, slot); p.zz = ldc(2, slot); p.zzz = ldc(3, slot);
         return p;
     };
-    if (t >= 128) put(acc);
+    // level 256 -> 128: one addition per lane
+    if (t >= 128) put(t, acc);
     __syncthreads();
-    if (t < 128) acc = g1_add(acc, get(t + 128));
-    if (t >= 64 && t < 128) put(acc);              // slots [64,128): nobody reads them before the barrier
-    __syncthreads();
-    if (t < 64) {
-        acc = g1_add(acc, get(t + 64));
-        for (int mask = 32; mask >= 1; mask >>= 1) acc = g1_add(acc, shfl_xor_point(acc, mask));
+    if (t < 128) {
+        acc = g1_add(acc, get(t + 128));
+        put(t, acc);
     }
-    return acc;
+    __syncthreads();
+    enum { V_U1 = 0, V_S1, V_U2, V_S2, V_PPU, V_PP, V_RR, V_RR2, V_ZZ12, V_ZZZ12, V_PPP, V_QQ };
+    const uint32_t q = t >> 2, j = t & 3;
+    for (uint32_t m = 64; m >= 1; m >>= 1) {
+        const bool act = t < 4 * m;
+        const uint32_t a = q, b = q + m;
+        Fq mine = Fq::zero(), keep = Fq::zero();
+        // R1: u1 | s1 | u2 | s2
+        Fq A1 = Fq::zero(), B1 = Fq::zero();
+        if (act) {
+            A1 = ldc(j & 1, (j & 2) ? b : a);                    // x or y of P (lanes 0,1) / of Q (lanes 2,3)
+            B1 = ldc(2 + (j & 1), (j & 2) ? a : b);              // zz or zzz of the OTHER point
+        }
+        mine = A1 * B1;
+        if (act) sts(V_U1 + j, q, mine);
+        __syncthreads();
+        // Every round is ONE product executed by all four lanes on lane-selected operands: the
+        // selection diverges (a few LDS reads), the ~340-instruction product never does.
+        // R2: pp_, pp | rr, rr2 | zz12 | zzz12
+        Fq A2 = Fq::zero(), B2 = Fq::zero();
+        if (act) {
+            if (j < 2) {
+                A2 = lds(V_U2 + j, q) - mine;                    // pp_ = u2 - u1 (lane 0), rr = s2 - s1 (lane 1)
+                B2 = A2;
+                sts(j == 0 ? V_PPU : V_RR, q, A2);
+                if (j == 0) {
+                    const Fq z1 = ldc(2, a), z2 = ldc(2, b);
+                    flg[q] = (z1.is_zero() ? 1u : 0u) | (z2.is_zero() ? 2u : 0u) | (A2.is_zero() ? 4u : 0u);
+                }
+            } else {
+                A2 = ldc(j, a);                                  // zz1, zz2 (lane 2) / zzz1, zzz2 (lane 3)
+                B2 = ldc(j, b);
+            }
+        }
+        keep = A2 * B2;                                          // pp | rr2 | zz12 | zzz12
+        if (act && j < 2) sts(j == 0 ? V_PP : V_RR2, q, keep);
+        __syncthreads();
+        // R3: qq = u1 pp | - | zz3 = zz12 pp | ppp = pp_ pp
+        Fq A3 = Fq::zero(), B3 = Fq::zero();
+        if (act) {
+            B3 = lds(V_PP, q);
+            A3 = j == 0 ? mine : keep;                           // lane 0: u1; lane 2: zz12; (lane 1: unused)
+            if (j == 3) A3 = lds(V_PPU, q);
+        }
+        const Fq r3 = A3 * B3;                                   // qq | - | zz3 | ppp
+        if (act && j == 3) sts(V_PPP, q, r3);
+        __syncthreads();
+        // R4: x3, t2 = rr (qq - x3) | t1 = s1 ppp | - | zzz3 = zzz12 ppp
+        Fq A4 = Fq::zero(), B4 = Fq::zero(), out = r3;           // lane 2: zz3
+        if (act) {
+            if (j == 0) {
+                out = lds(V_RR2, q) - lds(V_PPP, q) - Fq::dbl(r3);   // x3
+                A4 = lds(V_RR, q);
+                B4 = r3 - out;
+            } else if (j == 1) {
+                A4 = mine;                                       // s1
+                B4 = lds(V_PPP, q);
+            } else if (j == 3) {
+                A4 = keep;                                       // zzz12
+                B4 = r3;                                         // ppp
+            }
+        }
+        const Fq r4 = A4 * B4;                                   // t2 | t1 | - | zzz3
+        if (act && j == 0) sts(V_U2, q, r4);                     // t2 (the u2 slot is free by now)
+        if (j == 3) out = r4;
+        __syncthreads();
+        // R5: y3, select around identities, write the sum into slot a
+        bool special = false;
+        if (act) {
+            const uint32_t f = flg[q];
+            if (j == 1) out = lds(V_U2, q) - r4;                 // y3 = t2 - t1
+            if (f & 1u) stc(j, a, ldc(j, b));                    // P = O: the sum is Q
+            else if (f & 2u) { /* Q = O: the sum is P, already in slot a */ }
+            else if (f & 4u) special = true;                     // same x: doubling or opposite points
+            else stc(j, a, out);
+        }
+        if (__syncthreads_or(special ? 1 : 0)) {
+            if (act && j == 0 && special) put(a, g1_add(get(a), get(b)));
+            __syncthreads();
+        }
+    }
+    G1X r = G1X::inf();
+    if (t == 0) r = get(0);
+    return r;
 }
 
 // lane <-> scalar i, blockIdx.y <-> group of T windows, blockIdx.z <-> MSM of the batch
 __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a) {
-    __shared__ uint32_t sh[32 * MSM_THREADS];
+    __shared__ uint32_t sh[COOP_LDS_WORDS];
     const size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x;
     const uint32_t seg = blockIdx.z >= a.split ? 1u : 0u;
     const uint32_t m = blockIdx.z - (seg ? a.split : 0u);
@@ -457,7 +568,7 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
 
 // one workgroup per MSM: sum of its P partials
 __global__ __launch_bounds__(MSM_THREADS) void msm_direct_final_kernel(const G1X* partials, uint32_t P, G1X* out) {
-    __shared__ uint32_t sh[32 * MSM_THREADS];
+    __shared__ uint32_t sh[COOP_LDS_WORDS];
     const uint32_t m = blockIdx.x;
     const G1X* p = partials + (size_t)m * P;
     G1X acc = G1X::inf();

@@ -64,7 +64,11 @@ __device__ __forceinline__ void gstore(Fr* p, const Fr& v) {
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassParams p) {
+// THREADS = 256 when the launch has workgroups to spare (8 elements per thread), 1024 for the prover's
+// small batches (2 elements per thread: the same work on four times the waves, a quarter of the
+// dependent chain per stage -- these launches are bound by the issue rate of a lone wave)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
     __shared__ uint4 sh_lo[1 << NTT_TILE_LOG];
     __shared__ uint4 sh_hi[1 << NTT_TILE_LOG];
     const uint32_t tid = threadIdx.x;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassParams p) {
     }
 
     // ---- load HBM -> LDS
-    for (uint32_t e = tid; e < E; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < E; e += THREADS) {
         size_t gi;
         uint32_t li;
         if (!p.is_final) {
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassParams p) {
     // ---- s decimation-in-frequency stages in LDS
     for (int t = (int)s - 1; t >= 0; t--) {
         const uint32_t half = 1u << t;
-        for (uint32_t b = tid; b < (E >> 1); b += NTT_THREADS) {
+        for (uint32_t b = tid; b < (E >> 1); b += THREADS) {
             uint32_t v = b & (V - 1), jb = b >> c;
             uint32_t grp = jb >> t, pos = jb & (half - 1);
             uint32_t j0 = (grp << (t + 1)) | pos;
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassParams p) {
 
     // ---- store LDS -> HBM (bit reversal folded into the LDS read index)
     const uint32_t hi_bits = p.log_n - s - p.lo_bits;
-    for (uint32_t e = tid; e < E; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < E; e += THREADS) {
         uint32_t v = e & (V - 1), kp = e >> c;
         uint32_t j = s ? (__brev(kp) >> (32 - s)) : 0;
         Fr val = lds_load(sh_lo, sh_hi, j * V + v);
@@ -305,7 +309,10 @@ void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_
         if (p.is_final) { p.dst = d_out; p.dst_stride = N; }
         else { p.dst = tmp; p.dst_stride = N; }
         uint32_t tiles = (uint32_t)(N >> (p.s + p.c));
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, batch), dim3(NTT_THREADS), 0, st, p);
+        if ((uint64_t)tiles * batch <= (uint64_t)4 * ctx->num_cus)
+            hipLaunchKernelGGL(ntt_pass_kernel<1024>, dim3(tiles, batch), dim3(1024), 0, st, p);
+        else
+            hipLaunchKernelGGL(ntt_pass_kernel<NTT_THREADS>, dim3(tiles, batch), dim3(NTT_THREADS), 0, st, p);
         SHP_HIP(hipGetLastError());
         consumed += p.s;
     }
