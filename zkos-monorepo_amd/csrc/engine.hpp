@@ -59,12 +59,13 @@ struct KernelTimers {
 // per-caller scratch of one MSM pipeline (a prover instance owns one per stream)
 struct MsmWorkspace {
     KernelTimers* timers = nullptr;
-    DevBuf cnt, start, entries, pf, pl, buckets, out;
+    DevBuf cnt, start, entries, pf, pl, buckets, out, wg_hist;
     std::vector<G1X> h_out;
     std::vector<uint32_t> h_totals;
     uint64_t last_adds = 0, last_bytes = 0;
     void release() {
         cnt.release(); start.release(); entries.release(); pf.release(); pl.release(); buckets.release(); out.release();
+        wg_hist.release();
     }
 };
 

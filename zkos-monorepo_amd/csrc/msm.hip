@@ -21,6 +21,7 @@
 //   * The handful of final XYZZ sums are normalised on the host (needed there anyway for the
 //     Keccak transcript).
 #include <algorithm>
+#include <mutex>
 #include <stdlib.h>
 
 #include "engine.hpp"
@@ -66,36 +67,70 @@ __global__ void msm_table_kernel(const G1Affine* bases, G1Affine* table, size_t 
     }
 }
 
-// ---------------------------------------------------------------- digits: count / scatter
+// ---- counting sort by bucket without global atomics -----------------------------------------
+// (2^24 scalars x 16 windows = 268 M increments on 32768 counters: as global atomics that was 43 %
+// of the whole MSM.)  Each workgroup owns a contiguous range of scalars and keeps the bucket
+// histogram in LDS (NB + 1 words: 128 KB at c = 16, one workgroup per CU):
+//   msm_hist_kernel        LDS histogram of my range                 -> wg_hist[m][wg][b]
+//   msm_hist_prefix_kernel per bucket: exclusive prefix over the workgroups (in place), total -> cnt
+//   msm_scan_kernel        bucket starts from the totals (as before)
+//   msm_scatter_kernel     LDS cursors start[b] + wg_hist[m][wg][b]; digits again, entries written
+// The order of the entries inside a bucket depends on the LDS atomics' arrival order; the bucket
+// SUM does not (exact group arithmetic), so results stay bit-identical.
+constexpr int DIG_THREADS = 1024;
+
 template <bool SCATTER>
-__global__ void msm_digits_kernel(const Fr* scalars, size_t n_scalars, size_t stride, size_t n_table, uint32_t c,
-                                  uint32_t W, uint32_t NB, uint32_t* cnt, const uint32_t* start, uint32_t* entries,
-                                  size_t entries_stride) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t m = blockIdx.y;
-    if (i >= n_scalars) return;
-    Fr raw = load_fr(scalars + (size_t)m * stride + i).to_raw();
-    if (raw.is_zero()) return;
-    uint32_t* my_cnt = cnt + (size_t)m * (NB + 2);
-    const uint32_t* my_start = SCATTER ? start + (size_t)m * (NB + 2) : nullptr;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < W; w++) {
-        uint32_t d = raw_bits(raw, w * c, c) + carry;
-        uint32_t sign = 0;
-        carry = 0;
-        if (d > NB) {
-            d = (1u << c) - d;
-            sign = 1;
-            carry = 1;
-        }
-        if (d == 0) continue;
-        if (!SCATTER) {
-            atomicAdd(&my_cnt[d], 1u);
-        } else {
-            uint32_t pos = my_start[d] + atomicAdd(&my_cnt[d], 1u);
-            entries[(size_t)m * entries_stride + pos] = (uint32_t)((size_t)w * n_table + i) | (sign << 31);
+__global__ __launch_bounds__(DIG_THREADS) void msm_hist_kernel(const Fr* scalars, size_t n_scalars, size_t stride, size_t n_table,
+                                                               uint32_t c, uint32_t W, uint32_t NB, uint32_t* wg_hist,
+                                                               const uint32_t* start, uint32_t* entries, size_t entries_stride) {
+    extern __shared__ uint32_t lds_cnt[];                       // NB + 1 words
+    const uint32_t G = gridDim.x, wg = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+    uint32_t* row = wg_hist + ((size_t)m * G + wg) * (NB + 1);
+    if (SCATTER) {
+        const uint32_t* st = start + (size_t)m * (NB + 2);
+        for (uint32_t b = tid; b <= NB; b += DIG_THREADS) lds_cnt[b] = st[b] + row[b];
+    } else {
+        for (uint32_t b = tid; b <= NB; b += DIG_THREADS) lds_cnt[b] = 0;
+    }
+    __syncthreads();
+    const size_t per = (n_scalars + G - 1) / G;
+    const size_t i0 = (size_t)wg * per, i1 = i0 + per < n_scalars ? i0 + per : n_scalars;
+    for (size_t i = i0 + tid; i < i1; i += DIG_THREADS) {
+        Fr raw = load_fr(scalars + (size_t)m * stride + i).to_raw();
+        if (raw.is_zero()) continue;
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < W; w++) {
+            uint32_t d = raw_bits(raw, w * c, c) + carry;
+            uint32_t sign = 0;
+            carry = 0;
+            if (d > NB) {
+                d = (1u << c) - d;
+                sign = 1;
+                carry = 1;
+            }
+            if (d == 0) continue;
+            const uint32_t pos = atomicAdd(&lds_cnt[d], 1u);
+            if (SCATTER) entries[(size_t)m * entries_stride + pos] = (uint32_t)((size_t)w * n_table + i) | (sign << 31);
         }
     }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t b = tid; b <= NB; b += DIG_THREADS) row[b] = lds_cnt[b];
+    }
+}
+
+// thread <-> bucket: exclusive prefix of wg_hist[m][.][b] over the workgroups, total into cnt[m][b]
+__global__ void msm_hist_prefix_kernel(uint32_t* wg_hist, uint32_t G, uint32_t NB, uint32_t* cnt) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (b > NB) return;
+    uint32_t* col = wg_hist + (size_t)m * G * (NB + 1) + b;
+    uint32_t run = 0;
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t v = col[(size_t)g * (NB + 1)];
+        col[(size_t)g * (NB + 1)] = run;
+        run += v;
+    }
+    cnt[(size_t)m * (NB + 2) + b] = run;
 }
 
 // exclusive scan of cnt[m][1..NB] -> start[m][1..NB+1]; one workgroup per batch element
@@ -235,12 +270,16 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_fixup_kernel(const uint32_t* 
 }
 
 // ---------------------------------------------------------------- sum_b b * B_b
-__global__ __launch_bounds__(MSM_THREADS) void msm_reduce_kernel(const G1X* buckets, uint32_t NB, G1X* out) {
+// The buckets are cut into slices of Q = 256 g consecutive buckets, one workgroup each: slice w
+// returns L_w = sum_l l * B_(wQ+l) (running sums per thread, LDS suffix scan, tree) and its plain
+// sum R_w; the combine kernel adds sum_w L_w + Q * sum_w w R_w (Q a power of two: doublings).
+// A single workgroup over all 2^15 buckets of a c = 16 plan spent 2.5 ms here whatever the MSM size.
+__global__ __launch_bounds__(MSM_THREADS) void msm_reduce_kernel(const G1X* buckets, uint32_t NB, uint32_t Q, G1X* outL, G1X* outR) {
     __shared__ G1X sh[2][MSM_THREADS];
-    const uint32_t t = threadIdx.x, m = blockIdx.x;
-    const G1X* bk = buckets + (size_t)m * (NB + 1);
-    const uint32_t A = NB < MSM_THREADS ? NB : MSM_THREADS;
-    const uint32_t g = NB / A;
+    const uint32_t t = threadIdx.x, w = blockIdx.x, m = blockIdx.y;
+    const G1X* bk = buckets + (size_t)m * (NB + 1) + (size_t)w * Q;
+    const uint32_t A = Q < MSM_THREADS ? Q : MSM_THREADS;
+    const uint32_t g = Q / A;
     G1X run = G1X::inf(), V = G1X::inf();
     if (t < A) {
         for (int j = (int)g - 1; j >= 0; j--) {
@@ -259,6 +298,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_reduce_kernel(const G1X* buck
         cur ^= 1;
         __syncthreads();
     }
+    if (t == 0) outR[(size_t)m * gridDim.x + w] = sh[cur][0];
     G1X Y = V;
     if (t >= 1 && t < A) {
         G1X S = sh[cur][t];
@@ -272,7 +312,35 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_reduce_kernel(const G1X* buck
         if (t < off) sh[0][t] = g1_add(sh[0][t], sh[0][t + off]);
         __syncthreads();
     }
-    if (t == 0) out[m] = sh[0][0];
+    if (t == 0) outL[(size_t)m * gridDim.x + w] = sh[0][0];
+}
+
+// one wave per MSM: sum_w L_w + Q * sum_w w * R_w over nW <= 64 slices
+__global__ __launch_bounds__(64) void msm_reduce_combine_kernel(const G1X* L, const G1X* R, uint32_t nW, uint32_t Q, G1X* out) {
+    const uint32_t lane = threadIdx.x, m = blockIdx.x;
+    G1X l = G1X::inf(), s = G1X::inf();
+    if (lane < nW) {
+        l = L[(size_t)m * nW + lane];
+        s = R[(size_t)m * nW + lane];
+    }
+    // inclusive suffix sums S_w = sum_{w' >= w} R_w' ; sum_w w R_w = sum_{w >= 1} S_w
+    for (int off = 1; off < 64; off <<= 1) {
+        G1X o;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&s);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+        for (int i = 0; i < 32; i++) dst[i] = __shfl_down(src[i], off);
+        if ((int)lane + off < 64 && (uint32_t)off < nW) s = g1_add(s, o);
+    }
+    if (lane == 0) s = G1X::inf();
+    for (int mask = 32; mask >= 1; mask >>= 1) {
+        if ((uint32_t)mask < nW || mask == 1) {
+            s = g1_add(s, shfl_xor_point(s, mask));
+            l = g1_add(l, shfl_xor_point(l, mask));
+        }
+    }
+    for (uint32_t k = Q; k > 1; k >>= 1) s = g1_dbl(s);
+    if (lane == 0) out[m] = g1_add(l, s);
 }
 
 // ================================================================== direct-table mode
@@ -761,12 +829,15 @@ void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n
     }
     const uint32_t NB = m->NB, W = m->W;
     const size_t entries_stride = n_scalars * W;
-    const uint32_t T = entries_stride >= ((size_t)1 << 22) ? 64 : 16;
+    // entries per accumulation chunk: long chunks for huge inputs keep the number of partials per bucket
+    // (merged by msm_fixup_kernel, one lane per bucket) small while every SIMD still has several waves
+    const uint32_t T = entries_stride >= ((size_t)1 << 26) ? 256 : entries_stride >= ((size_t)1 << 22) ? 64 : 16;
     const uint32_t chunks = ceil_div(entries_stride, T);
     ws.cnt.reserve((size_t)batch * (NB + 2) * 4);
     ws.start.reserve((size_t)batch * (NB + 2) * 4);
     ws.entries.reserve((size_t)batch * entries_stride * 4);
-    ws.pf.reserve((size_t)batch * chunks * sizeof(Partial));
+    const uint32_t red_Q = NB < 2048 ? NB : 2048, red_nW = NB / red_Q;   // slices of the bucket reduction
+    ws.pf.reserve(std::max((size_t)batch * chunks * sizeof(Partial), (size_t)batch * 2 * red_nW * sizeof(G1X)));
     ws.pl.reserve((size_t)batch * chunks * sizeof(Partial));
     ws.buckets.reserve((size_t)batch * (NB + 1) * sizeof(G1X));
     ws.out.reserve((size_t)batch * sizeof(G1X));
@@ -776,16 +847,26 @@ void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n
     G1X* buckets = ws.buckets.as<G1X>();
 
     KernelTimers none, *tm = ws.timers ? ws.timers : &none;
+    // counting sort by bucket: LDS histograms per workgroup, no global atomics
+    const uint32_t G = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)m->ctx->num_cus, ceil_div(n_scalars, DIG_THREADS)));
+    const size_t lds_bytes = (size_t)(NB + 1) * 4;
+    SHP_REQUIRE(lds_bytes <= 160 * 1024 - 512, SHP_ERR_INVALID_ARG, "msm: window too wide for the LDS histogram (c <= 16)");
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute((const void*)msm_hist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void*)msm_hist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    });
+    ws.wg_hist.reserve((size_t)batch * G * (NB + 1) * 4);
+    uint32_t* wg_hist = ws.wg_hist.as<uint32_t>();
     SHP_HIP(hipMemsetAsync(cnt, 0, (size_t)batch * (NB + 2) * 4, st));
-    dim3 gd(ceil_div(n_scalars, MSM_THREADS), batch);
     tm->begin(KID_MSM_DIGITS, st);
-    hipLaunchKernelGGL(msm_digits_kernel<false>, gd, dim3(MSM_THREADS), 0, st, d_scalars, n_scalars, stride, m->n, m->c,
-                       W, NB, cnt, (const uint32_t*)nullptr, (uint32_t*)nullptr, entries_stride);
-    tm->end(st);
+    hipLaunchKernelGGL(msm_hist_kernel<false>, dim3(G, batch), dim3(DIG_THREADS), lds_bytes, st, d_scalars, n_scalars, stride,
+                       m->n, m->c, W, NB, wg_hist, (const uint32_t*)nullptr, (uint32_t*)nullptr, entries_stride);
+    hipLaunchKernelGGL(msm_hist_prefix_kernel, dim3(ceil_div(NB + 1, 256), batch), dim3(256), 0, st, wg_hist, G, NB, cnt);
     hipLaunchKernelGGL(msm_scan_kernel, dim3(batch), dim3(MSM_THREADS), 0, st, cnt, start, NB);
-    SHP_HIP(hipMemsetAsync(cnt, 0, (size_t)batch * (NB + 2) * 4, st));
-    hipLaunchKernelGGL(msm_digits_kernel<true>, gd, dim3(MSM_THREADS), 0, st, d_scalars, n_scalars, stride, m->n, m->c,
-                       W, NB, cnt, start, entries, entries_stride);
+    hipLaunchKernelGGL(msm_hist_kernel<true>, dim3(G, batch), dim3(DIG_THREADS), lds_bytes, st, d_scalars, n_scalars, stride,
+                       m->n, m->c, W, NB, wg_hist, start, entries, entries_stride);
+    tm->end(st);
     SHP_HIP(hipMemsetAsync(buckets, 0, (size_t)batch * (NB + 1) * sizeof(G1X), st));
     tm->begin(KID_MSM_ACCUMULATE, st);
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(ceil_div(chunks, MSM_THREADS), batch), dim3(MSM_THREADS), 0, st,
@@ -797,7 +878,13 @@ void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n
                        chunks, buckets, ws.pf.as<Partial>(), ws.pl.as<Partial>());
     tm->end(st);
     tm->begin(KID_MSM_REDUCE, st);
-    hipLaunchKernelGGL(msm_reduce_kernel, dim3(batch), dim3(MSM_THREADS), 0, st, buckets, NB, ws.out.as<G1X>());
+    {
+        const uint32_t Q = red_Q, nW = red_nW;                           // powers of two, nW <= 16 (c <= 16)
+        G1X* L = ws.pf.as<G1X>();                                        // the partials are dead by now: reuse as L | R
+        G1X* Rr = L + (size_t)batch * nW;
+        hipLaunchKernelGGL(msm_reduce_kernel, dim3(nW, batch), dim3(MSM_THREADS), 0, st, buckets, NB, Q, L, Rr);
+        hipLaunchKernelGGL(msm_reduce_combine_kernel, dim3(batch), dim3(64), 0, st, L, Rr, nW, Q, ws.out.as<G1X>());
+    }
     tm->end(st);
     SHP_HIP(hipGetLastError());
     ws.h_out.resize(batch);
