@@ -201,13 +201,56 @@ def test_msm_2_20_matches_oracle(shp, oracle, gpu_ctx):
     # distinct-enough bases: tile the 8192 synthetic points (the MSM does not care about repeats)
     bases = np.tile(osrs.g, (reps, 1))
     s = rand_fr(oracle, n, 2020)
+    import time
     m = shp.Msm(gpu_ctx, bases)
-    got = m.run(shp.to_device(s), n, 1)[0]
-    assert np.array_equal(got, oracle.msm(bases, s))
+    ts = shp.to_device(s)
+    got = m.run(ts, n, 1)[0]
     adds, nbytes = m.stats()
     assert nbytes == 96 * n and adds > 0
+    t0 = time.perf_counter()
+    for _ in range(3):
+        m.run(ts, n, 1)
+    gpu_s = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter(); want = oracle.msm(bases, s); cpu_s = time.perf_counter() - t0
+    assert np.array_equal(got, want)
+    _record("config4_msm_2_20", {"n": n, "gpu_ms": 1e3 * gpu_s, "cpu_port_ms": 1e3 * cpu_s, "cpu_threads": oracle.num_threads(),
+                                  "speedup": cpu_s / gpu_s, "alg_GBps": 96 * n / gpu_s / 1e9})
     m.close()
     del torch
+
+
+def _record(name, obj):
+    """GPU-vs-CPU-port timings of the standalone configs, kept with the run's other outputs"""
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "micro_vs_cpu.jsonl"), "a") as f:
+            f.write(json.dumps({"config": name, **obj}) + "\n")
+    except OSError:
+        pass
+
+
+def test_ntt_2_20_vs_cpu_port(shp, oracle, gpu_ctx):
+    """BASELINE config 5 lower size: parity with the oracle and the GPU / CPU-port timing"""
+    import time
+    import torch
+    log_n, n = 20, 1 << 20
+    a = rand_fr(oracle, n, 55)
+    t = shp.to_device(a)
+    gpu_ctx.ntt(t, log_n)
+    got = shp.to_host(t).reshape(n, 4).copy()
+    # GPU timing first: the OpenMP oracle leaves its threads spinning for a while afterwards
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        gpu_ctx.ntt(t, log_n)
+    torch.cuda.synchronize()
+    gpu_s = (time.perf_counter() - t0) / 10
+    t0 = time.perf_counter(); want = oracle.ntt(a, log_n); cpu_s = time.perf_counter() - t0
+    assert np.array_equal(got, want)
+    _record("config5_ntt_2_20", {"n": n, "gpu_ms": 1e3 * gpu_s, "cpu_port_ms": 1e3 * cpu_s, "cpu_threads": oracle.num_threads(),
+                                  "speedup": cpu_s / gpu_s, "alg_GBps": 64 * n / gpu_s / 1e9})
 
 
 def test_merkle_tree_matches_contract_semantics(shp, oracle, gpu_ctx):

@@ -24,7 +24,7 @@ def main():
     import torch
     ap = argparse.ArgumentParser()
     ap.add_argument("--ntt", type=int, nargs="*", default=[13, 16, 20, 22, 24])
-    ap.add_argument("--msm", type=int, nargs="*", default=[13, 16, 20])
+    ap.add_argument("--msm", type=int, nargs="*", default=[13, 16, 20, 22, 24])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--window", type=int, default=0)
     a = ap.parse_args()
