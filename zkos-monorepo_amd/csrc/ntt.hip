@@ -19,6 +19,8 @@
 //   * The last pass writes in digit-reversed = natural order, 2^c adjacent outputs per run,
 //     so there is no separate bit-reversal sweep.  1/n, and the zeta-coset scalings of
 //     coeff_to_extended / extended_to_coeff, are fused into the first load / last store.
+#include <stdlib.h>
+
 #include "ctx.hpp"
 
 namespace shp {
@@ -64,7 +66,7 @@ __device__ __forceinline__ void gstore(Fr* p, const Fr& v) {
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-// THREADS = 256 when the launch has workgroups to spare (8 elements per thread), 1024 for the prover's
+// THREADS = 512 when the launch has workgroups to spare (4 elements per thread), 1024 for the prover's
 // small batches (2 elements per thread: the same work on four times the waves, a quarter of the
 // dependent chain per stage -- these launches are bound by the issue rate of a lone wave)
 template <int THREADS>
@@ -309,10 +311,15 @@ void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_
         if (p.is_final) { p.dst = d_out; p.dst_stride = N; }
         else { p.dst = tmp; p.dst_stride = N; }
         uint32_t tiles = (uint32_t)(N >> (p.s + p.c));
-        if ((uint64_t)tiles * batch <= (uint64_t)4 * ctx->num_cus)
+        static const int forced = getenv("SHP_NTT_THREADS") ? atoi(getenv("SHP_NTT_THREADS")) : 0;   // tuning aid
+        int threads = (uint64_t)tiles * batch <= (uint64_t)4 * ctx->num_cus ? 1024 : 512;   // measured: 2^24 3.07 ms (256) / 2.82 (512) / 3.02 (1024)
+        if (forced == 256 || forced == 512 || forced == 1024) threads = forced;
+        if (threads == 1024)
             hipLaunchKernelGGL(ntt_pass_kernel<1024>, dim3(tiles, batch), dim3(1024), 0, st, p);
+        else if (threads == 512)
+            hipLaunchKernelGGL(ntt_pass_kernel<512>, dim3(tiles, batch), dim3(512), 0, st, p);
         else
-            hipLaunchKernelGGL(ntt_pass_kernel<NTT_THREADS>, dim3(tiles, batch), dim3(NTT_THREADS), 0, st, p);
+            hipLaunchKernelGGL(ntt_pass_kernel<256>, dim3(tiles, batch), dim3(256), 0, st, p);
         SHP_HIP(hipGetLastError());
         consumed += p.s;
     }
