@@ -190,6 +190,11 @@ int32_t shp_prover_destroy(shp_prover* p);
 int32_t shp_prove(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, const uint8_t seed[32],
                   uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* instances_le32,
                   size_t instances_cap);
+/* Host threads the lane uses for the witness program (the reference's `synthesize`, rayon in its
+ * multithreading feature): the program is cut into independent tasks once per lane (Poseidon2
+ * permutations of the Merkle levels run side by side).  Default 4 (env SHP_WITNESS_THREADS); a
+ * proving pool with more than 4 lanes sets 1 -- throughput does not need it, latency does. */
+int32_t shp_prover_witness_threads(shp_prover* p, uint32_t threads);
 /* HIP-event timing of the lane's kernel launches, on the stream they run on: enable (resets the
  * counters), prove, then read entry `index` (0 .. until SHP_ERR_INVALID_ARG): kernel family name,
  * number of launches, summed duration. */

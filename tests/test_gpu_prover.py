@@ -250,3 +250,20 @@ def test_deposit_shaped_plan_proof_bytes(shp, oracle, gpu_ctx):
     assert inst[3:6] == [wit[lay.VALUE], wit[lay.COMMITMENT], wit[lay.TOKEN]]
     assert PL.verify(opk, proof, inst, tau=TAU)
     pr.close(); pk.close(); params.close()
+
+
+@pytest.mark.parametrize("small", [True, False])
+def test_witness_schedule_threads_give_identical_proofs(shp, oracle, gpu_ctx, small):
+    """the witness program cut into parallel tasks (1, 2, 4, 7 host threads) yields the same proof bytes as
+    the sequential program and as the oracle"""
+    PL, C, plan, lay, osrs, opk, params, pk = setup(shp, oracle, gpu_ctx, small)
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    bal, val = (2**31 + 5, 2**20 + 3) if small else (10**18, 10**17)
+    wit = C.withdraw_witness_inputs(lay, H, random.Random(8), bal, val)
+    pr = shp.Prover(pk)
+    want = PL.prove(opk, osrs, wit, bytes([5]) * 32)
+    for threads in (1, 2, 4, 7, 4):
+        pr.witness_threads(threads)
+        for _ in range(3):
+            assert pr.prove(wit, bytes([5]) * 32) == want, f"{threads} witness threads"
+    pr.close(); pk.close(); params.close()

@@ -336,6 +336,10 @@ class Prover:
         ins = [int.from_bytes(inst.raw[32 * i:32 * i + 32], "little") for i in range(self.pk.n_instances)]
         return proof.raw[:plen.value], ins
 
+    def witness_threads(self, n: int):
+        """host threads for the witness program of this lane (default 4; 1 = sequential)"""
+        _check(lib().shp_prover_witness_threads(self.h, C.c_uint32(n)))
+
     def profile(self, enable=True):
         _check(lib().shp_prover_profile(self.h, C.c_int32(1 if enable else 0)))
 

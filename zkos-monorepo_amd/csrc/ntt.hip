@@ -26,7 +26,6 @@
 namespace shp {
 
 constexpr int NTT_TILE_LOG = 11;
-constexpr int NTT_THREADS = 256;
 
 struct PassParams {
     const Fr* src;

@@ -11,8 +11,12 @@
 // SURVEY.md Appendix B.  The host only sequences phases, hashes the transcript and handles
 // a few scalars per phase; every vector operation runs in HIP kernels.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <map>
+#include <memory>
+#include <thread>
 
 #include "prover_kernels.cuh"
 #include "poseidon2.cuh"
@@ -203,6 +207,244 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     *out = pk.release();
 }
 
+// P1: the plan's witness program over Montgomery values (SURVEY.md row a7 `synthesize`).
+// Ops [lo, hi) with a caller-owned scratch row.
+static void run_witness_range(const PlanData& P, const std::vector<Fr>& inputs, Fr* grid /* [A][n], pinned */, Fr* scratch,
+                              uint32_t lo, uint32_t hi) {
+    const uint32_t A = P.num_advice, n = P.n;
+    auto cell = [&](uint32_t c, uint32_t r) -> Fr& { return c == A ? scratch[r] : grid[(size_t)c * n + r]; };
+    for (uint32_t i = lo; i < hi; i++) {
+        const WOp& w = P.wops[i];
+        Fr v;
+        switch (w.op) {
+            case W_INPUT: v = inputs[w.imm]; break;
+            case W_CONST: v = P.consts[w.imm]; break;
+            case W_COPY: v = cell(w.ac, w.ar); break;
+            case W_ADD: v = cell(w.ac, w.ar) + cell(w.bc, w.br); break;
+            case W_SUB: v = cell(w.ac, w.ar) - cell(w.bc, w.br); break;
+            case W_MUL: v = cell(w.ac, w.ar) * cell(w.bc, w.br); break;
+            case W_ADDC: v = cell(w.ac, w.ar) + P.consts[w.imm]; break;
+            case W_MULC: v = cell(w.ac, w.ar) * P.consts[w.imm]; break;
+            case W_POW7: {
+                Fr x = cell(w.ac, w.ar), x2 = Fr::sqr(x), x3 = x2 * x;
+                v = Fr::sqr(x3) * x;
+                break;
+            }
+            case W_BITS: case W_SHR: {
+                Fr raw = cell(w.ac, w.ar).to_raw(), o = Fr::zero();
+                if (w.op == W_BITS) {
+                    for (uint32_t b = 0; b < w.imm; b++) o.l[b >> 5] |= raw.l[b >> 5] & (1u << (b & 31));
+                } else {
+                    for (uint32_t b = w.imm; b < 256; b++)
+                        if ((raw.l[b >> 5] >> (b & 31)) & 1) o.l[(b - w.imm) >> 5] |= 1u << ((b - w.imm) & 31);
+                }
+                v = Fr::from_raw(o);
+                break;
+            }
+            default: throw Error(SHP_ERR_FORMAT, "witness: bad op");
+        }
+        cell(w.dc, w.dr) = v;
+    }
+}
+
+// ---- witness schedule: the program cut into tasks that may run on several host threads ------
+// The witness program is a straight-line list of cell operations; at k = 13 it is ~40 k operations
+// (19 Poseidon2 permutations) = 0.44 ms of a 3.5 ms proof on one core, and most of it is independent
+// work (the 13 Merkle levels hash given inputs).  Built once per key:
+//   * a scratch cell that is written and read later makes the ops in between one RUN; ops outside
+//     any run are glue (copies, inputs);
+//   * adjacent scratch runs that depend directly on each other (the rounds of one permutation) merge
+//     into one task; glue stays separate, so a copy between two permutations does not chain them;
+//   * tasks get levels from their advice-cell dependencies (RAW, WAR, WAW); a level's tasks are spread
+//     over the threads by size.  Every task runs its ops in program order with a private scratch row,
+//     so the values are those of the sequential program.
+struct WitnessSchedule {
+    struct Range { uint32_t lo, hi; };
+    uint32_t n_threads = 1;
+    std::vector<std::vector<std::vector<Range>>> plan;      // [level][thread] -> ranges
+
+    void build(const PlanData& P, uint32_t threads) {
+        n_threads = threads;
+        plan.clear();
+        const uint32_t A = P.num_advice, n = P.n, nops = (uint32_t)P.wops.size();
+        if (threads <= 1 || nops == 0) return;
+        auto reads = [&](const WOp& w, uint32_t out[2][2]) -> int {
+            switch (w.op) {
+                case W_INPUT: case W_CONST: return 0;
+                case W_ADD: case W_SUB: case W_MUL:
+                    out[0][0] = w.ac; out[0][1] = w.ar; out[1][0] = w.bc; out[1][1] = w.br; return 2;
+                default: out[0][0] = w.ac; out[0][1] = w.ar; return 1;
+            }
+        };
+        // 1. runs: cover[i] = true when a scratch value is live across the boundary i-1 | i
+        std::vector<int32_t> sc_writer(std::max<uint32_t>(P.n_wscratch, 1), -1);
+        std::vector<int32_t> diff(nops + 1, 0);
+        for (uint32_t i = 0; i < nops; i++) {
+            const WOp& w = P.wops[i];
+            uint32_t r[2][2];
+            int nr = reads(w, r);
+            for (int q = 0; q < nr; q++)
+                if (r[q][0] == A && sc_writer[r[q][1]] >= 0) { diff[sc_writer[r[q][1]] + 1]++; diff[i + 1]--; }
+            if (w.dc == A) sc_writer[w.dr] = (int32_t)i;
+        }
+        std::vector<uint8_t> joined(nops, 0);                  // op i is glued to op i-1 by live scratch
+        int32_t live = 0;
+        for (uint32_t i = 0; i < nops; i++) { live += diff[i]; joined[i] = live > 0; }
+        // groups of ops glued by live scratch are scratch runs; every other op is a glue op of its own
+        // (NOT merged with its neighbours: the copies between two permutations would chain them)
+        struct Run { uint32_t lo, hi; bool scratch; };
+        std::vector<Run> runs;
+        for (uint32_t i = 0; i < nops;) {
+            uint32_t j = i + 1;
+            while (j < nops && joined[j]) j++;
+            runs.push_back({i, j, j - i >= 2});
+            i = j;
+        }
+        // 2. tasks + advice-cell dependencies
+        struct Task { uint32_t lo, hi; bool scratch; uint32_t level; };
+        std::vector<Task> tasks;
+        std::vector<int32_t> last_writer((size_t)A * n, -1), last_reader((size_t)A * n, -1);
+        bool hazard = false;
+        auto deps_of = [&](uint32_t lo, uint32_t hi, std::vector<int32_t>& out) {
+            out.clear();
+            for (uint32_t i = lo; i < hi; i++) {
+                const WOp& w = P.wops[i];
+                uint32_t r[2][2];
+                int nr = reads(w, r);
+                for (int q = 0; q < nr; q++)
+                    if (r[q][0] < A) { int32_t t = last_writer[(size_t)r[q][0] * n + r[q][1]]; if (t >= 0) out.push_back(t); }
+                if (w.dc < A) {
+                    // the schedule relies on single assignment of advice cells: a second write, or a write
+                    // after a read of the still-empty cell, keeps the program sequential
+                    size_t c = (size_t)w.dc * n + w.dr;
+                    if (last_writer[c] >= 0 || last_reader[c] >= 0) hazard = true;
+                }
+            }
+        };
+        auto commit = [&](uint32_t lo, uint32_t hi, int32_t task) {
+            for (uint32_t i = lo; i < hi; i++) {
+                const WOp& w = P.wops[i];
+                uint32_t r[2][2];
+                int nr = reads(w, r);
+                for (int q = 0; q < nr; q++)
+                    if (r[q][0] < A) last_reader[(size_t)r[q][0] * n + r[q][1]] = task;
+                if (w.dc < A) last_writer[(size_t)w.dc * n + w.dr] = task;
+            }
+        };
+        std::vector<int32_t> deps;
+        std::vector<std::vector<int32_t>> task_deps;
+        for (const Run& r : runs) {
+            const int32_t prev = (int32_t)tasks.size() - 1;
+            deps_of(r.lo, r.hi, deps);
+            const bool on_prev = std::find(deps.begin(), deps.end(), prev) != deps.end();
+            if (prev >= 0 && r.scratch && tasks[prev].scratch && on_prev) {
+                tasks[prev].hi = r.hi;
+                for (int32_t d : deps) if (d != prev) task_deps[prev].push_back(d);
+                commit(r.lo, r.hi, prev);
+            } else {
+                tasks.push_back({r.lo, r.hi, r.scratch, 0});
+                task_deps.push_back(deps);
+                commit(r.lo, r.hi, (int32_t)tasks.size() - 1);
+            }
+        }
+        if (hazard) { n_threads = 1; return; }
+        uint32_t n_levels = 0;
+        for (size_t t = 0; t < tasks.size(); t++) {
+            uint32_t lv = 0;
+            for (int32_t d : task_deps[t]) if ((size_t)d != t) lv = std::max(lv, tasks[d].level + 1);
+            tasks[t].level = lv;
+            n_levels = std::max(n_levels, lv + 1);
+        }
+        // 3. per level: longest tasks first onto the least loaded thread
+        plan.assign(n_levels, std::vector<std::vector<Range>>(threads));
+        for (uint32_t lv = 0; lv < n_levels; lv++) {
+            std::vector<const Task*> at;
+            for (auto& t : tasks) if (t.level == lv) at.push_back(&t);
+            std::sort(at.begin(), at.end(), [](const Task* a, const Task* b) { return a->hi - a->lo > b->hi - b->lo; });
+            std::vector<uint64_t> load(threads, 0);
+            for (const Task* t : at) {
+                uint32_t best = 0;
+                for (uint32_t th = 1; th < threads; th++) if (load[th] < load[best]) best = th;
+                plan[lv][best].push_back({t->lo, t->hi});
+                load[best] += t->hi - t->lo;
+            }
+            // program order inside a thread (tasks of one level are independent, this is for locality)
+            for (auto& v : plan[lv]) std::sort(v.begin(), v.end(), [](const Range& a, const Range& b) { return a.lo < b.lo; });
+        }
+    }
+};
+
+// helper threads of one proving lane for the witness schedule (the caller is thread 0)
+struct WitnessWorkers {
+    uint32_t T = 1;
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<uint64_t> gen{0};
+    std::atomic<uint64_t> arrivals{0};        // monotonic: job base + (level + 1) * T is a level's barrier
+    bool stop = false;
+    // the job
+    const PlanData* P = nullptr;
+    const std::vector<Fr>* inputs = nullptr;
+    Fr* grid = nullptr;
+    const WitnessSchedule* sched = nullptr;
+    uint64_t base = 0;
+    std::vector<std::vector<Fr>> scratch;
+
+    WitnessWorkers(uint32_t threads, uint32_t n_scratch) : T(threads), scratch(threads, std::vector<Fr>(std::max<uint32_t>(n_scratch, 1), Fr::zero())) {
+        for (uint32_t t = 1; t < T; t++) th.emplace_back([this, t] { worker(t); });
+    }
+    ~WitnessWorkers() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            gen.fetch_add(1);
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void levels(uint32_t tid) {
+        const uint32_t nl = (uint32_t)sched->plan.size();
+        for (uint32_t lv = 0; lv < nl; lv++) {
+            for (const auto& r : sched->plan[lv][tid]) run_witness_range(*P, *inputs, grid, scratch[tid].data(), r.lo, r.hi);
+            arrivals.fetch_add(1, std::memory_order_acq_rel);
+            const uint64_t target = base + (uint64_t)(lv + 1) * T;
+            while (arrivals.load(std::memory_order_acquire) < target) std::this_thread::yield();
+        }
+    }
+    void worker(uint32_t tid) {
+        uint64_t seen = 0;
+        for (;;) {
+            // spin for a while (back-to-back proofs), then sleep
+            auto t0 = std::chrono::steady_clock::now();
+            while (gen.load(std::memory_order_acquire) == seen) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen; });
+                    break;
+                }
+                std::this_thread::yield();
+            }
+            seen = gen.load(std::memory_order_acquire);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (stop) return;
+            }
+            levels(tid);
+        }
+    }
+    void run(const PlanData& P_, const std::vector<Fr>& in, Fr* g, const WitnessSchedule& sc) {
+        P = &P_; inputs = &in; grid = g; sched = &sc;
+        base = arrivals.load(std::memory_order_acquire);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            gen.fetch_add(1, std::memory_order_acq_rel);
+        }
+        cv.notify_all();
+        levels(0);
+    }
+};
+
 // ------------------------------------------------------------------------------ prover instance
 struct shp_prover {
     shp_pk* pk = nullptr;
@@ -227,6 +469,9 @@ struct shp_prover {
     Fr *blinds = nullptr, *ntt_tmp = nullptr;
     uint32_t* key = nullptr;
     Fr* h_grid = nullptr;                                      // pinned host staging of the witness grid
+    WitnessSchedule wsched;                                    // witness program cut into parallel tasks
+    std::unique_ptr<WitnessWorkers> wworkers;
+    std::vector<Fr> wscratch;                                  // scratch row of the sequential path
     uint32_t* rank = nullptr;                                  // [2L][n] rank-sort scratch
     Fr *sc_pre = nullptr, *sc_suf = nullptr;                   // [SC][n] block-local scans
     Fr *sc_tot = nullptr;                                      // [6][SC][nb]: tot_a, tot_b, bpre_a, bsuf_b | [SC] inv
@@ -246,6 +491,14 @@ struct shp_prover {
         if (own_stream && st) (void)hipStreamDestroy(st);
     }
 };
+
+static void set_witness_threads(shp_prover* pr, uint32_t threads) {
+    threads = std::max<uint32_t>(1, std::min<uint32_t>(threads, 16));
+    pr->wworkers.reset();
+    pr->wsched.build(pr->pk->plan, threads);
+    if (pr->wsched.n_threads > 1 && !pr->wsched.plan.empty())
+        pr->wworkers.reset(new WitnessWorkers(pr->wsched.n_threads, pr->pk->plan.n_wscratch));
+}
 
 static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     SHP_REQUIRE(pk && out, SHP_ERR_INVALID_ARG, "prover_create: null argument");
@@ -287,58 +540,21 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->key = pr->dalloc<uint32_t>(8);
     pr->rank = pr->dalloc<uint32_t>((size_t)2 * L * n);
     SHP_HIP(hipHostMalloc((void**)&pr->h_grid, (size_t)(P.num_advice + 1) * n * sizeof(Fr), hipHostMallocDefault));
+    memset(pr->h_grid, 0, (size_t)(P.num_advice + 1) * n * sizeof(Fr));
     pr->sc_cnt = std::max<uint32_t>(S + L, MAX_POINTS);
     pr->sc_pre = pr->dalloc<Fr>((size_t)pr->sc_cnt * n);
     pr->sc_suf = pr->dalloc<Fr>((size_t)pr->sc_cnt * n);
     pr->sc_tot = pr->dalloc<Fr>((size_t)5 * pr->sc_cnt * SCAN_THREADS);
     pr->msm_ws.timers = &pr->timers;
+    pr->wscratch.assign(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
+    {
+        const char* e = getenv("SHP_WITNESS_THREADS");
+        set_witness_threads(pr.get(), e && *e ? (uint32_t)atoi(e) : 4);
+    }
     *out = pr.release();
 }
 
 // ------------------------------------------------------------------------------ host pieces
-// P1: the plan's witness program over Montgomery values (SURVEY.md row a7 `synthesize`)
-static void run_witness(const PlanData& P, const std::vector<Fr>& inputs, Fr* grid /* [A][n], pinned */,
-                        std::vector<Fr>& instances) {
-    const uint32_t A = P.num_advice, n = P.n;
-    memset(grid, 0, (size_t)A * n * sizeof(Fr));
-    std::vector<Fr> scratch(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
-    auto cell = [&](uint32_t c, uint32_t r) -> Fr& { return c == A ? scratch[r] : grid[(size_t)c * n + r]; };
-    for (const WOp& w : P.wops) {
-        Fr v;
-        switch (w.op) {
-            case W_INPUT: v = inputs[w.imm]; break;
-            case W_CONST: v = P.consts[w.imm]; break;
-            case W_COPY: v = cell(w.ac, w.ar); break;
-            case W_ADD: v = cell(w.ac, w.ar) + cell(w.bc, w.br); break;
-            case W_SUB: v = cell(w.ac, w.ar) - cell(w.bc, w.br); break;
-            case W_MUL: v = cell(w.ac, w.ar) * cell(w.bc, w.br); break;
-            case W_ADDC: v = cell(w.ac, w.ar) + P.consts[w.imm]; break;
-            case W_MULC: v = cell(w.ac, w.ar) * P.consts[w.imm]; break;
-            case W_POW7: {
-                Fr x = cell(w.ac, w.ar), x2 = Fr::sqr(x), x3 = x2 * x;
-                v = Fr::sqr(x3) * x;
-                break;
-            }
-            case W_BITS: case W_SHR: {
-                Fr raw = cell(w.ac, w.ar).to_raw(), o = Fr::zero();
-                if (w.op == W_BITS) {
-                    for (uint32_t b = 0; b < w.imm; b++) o.l[b >> 5] |= raw.l[b >> 5] & (1u << (b & 31));
-                } else {
-                    for (uint32_t b = w.imm; b < 256; b++)
-                        if ((raw.l[b >> 5] >> (b & 31)) & 1) o.l[(b - w.imm) >> 5] |= 1u << ((b - w.imm) & 31);
-                }
-                v = Fr::from_raw(o);
-                break;
-            }
-            default: throw Error(SHP_ERR_FORMAT, "witness: bad op");
-        }
-        cell(w.dc, w.dr) = v;
-    }
-    instances.resize(P.instance_map.size());
-    for (size_t i = 0; i < instances.size(); i++)
-        instances[i] = grid[(size_t)P.instance_map[i].first * n + P.instance_map[i].second];
-}
-
 namespace {
 struct PolyKey {
     int kind;       // 0 adv, 1 pz, 2 lz, 3 lpi, 4 lpt, 5 fix, 6 sig, 7 h, 8 rand
@@ -483,14 +699,19 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     }
     std::vector<Fr> instances;
     Fr* const grid = pr->h_grid;                        // pinned: [A][n] advice, then the instance column
-    run_witness(P, inputs, grid, instances);
+    // no per-proof clearing: the program writes the same cells every time (fixed plan), the blinding rows are
+    // redrawn below, everything else has been zero since prover_create
+    if (pr->wworkers) pr->wworkers->run(P, inputs, grid, pr->wsched);
+    else run_witness_range(P, inputs, grid, pr->wscratch.data(), 0, (uint32_t)P.wops.size());
+    instances.resize(P.instance_map.size());
+    for (size_t i = 0; i < instances.size(); i++)
+        instances[i] = grid[(size_t)P.instance_map[i].first * n + P.instance_map[i].second];
     pc.mark("run_witness");
     for (uint32_t c = 0; c < A; c++)
         for (uint32_t r = u; r < n; r++) grid[(size_t)c * n + r] = draw();
     pc.mark("blind_draws");
     ctr += A;                                           // one (unused) commitment blind per advice column
-    Fr* const instcol = grid + (size_t)A * n;
-    memset(instcol, 0, (size_t)n * sizeof(Fr));
+    Fr* const instcol = grid + (size_t)A * n;           // rows past the instances stay zero (cleared at creation)
     for (size_t i = 0; i < instances.size(); i++) instcol[i] = instances[i];
     SHP_HIP(hipMemcpyAsync(V(0), grid, (size_t)A * n * sizeof(Fr), hipMemcpyHostToDevice, st));
     SHP_HIP(hipMemcpyAsync(V(I_INST), instcol, (size_t)n * sizeof(Fr), hipMemcpyHostToDevice, st));
@@ -927,6 +1148,13 @@ int32_t shp_pk_commitments(const shp_pk* pk, void* h_fixed, size_t n_fixed, void
 
 int32_t shp_prover_create(shp_pk* pk, shp_prover** out) {
     return guarded([&] { prover_create_impl(pk, out); });
+}
+
+int32_t shp_prover_witness_threads(shp_prover* p, uint32_t threads) {
+    return guarded([&] {
+        SHP_REQUIRE(p, SHP_ERR_INVALID_ARG, "prover_witness_threads: null prover");
+        set_witness_threads(p, threads);
+    });
 }
 
 int32_t shp_prover_profile(shp_prover* p, int32_t enable) {
