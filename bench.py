@@ -33,6 +33,9 @@ sys.path.insert(0, ROOT)
 # proving lanes are HIP streams: give them hardware queues of their own (see zkos-monorepo_amd/binding.py);
 # must be in the environment before the HIP runtime initialises
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# the CPU baseline (OpenMP oracle) is fastest at the CPU share one GPU gets on this box: measured on the
+# MI355X host, ms per proof at 8 / 16 / 32 / 64 / 128 threads = 789 / 600 / 704 / 1001 / 1951
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 16)))
 
 HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 TAU = 0x2B6F1C0A94D3E5F7081A2B3C4D5E6F70_13
