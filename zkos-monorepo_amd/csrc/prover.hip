@@ -764,11 +764,13 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
                                pr->sort_raw + (size_t)(2 * l + 1) * n, u);
         }
         pr->timers.begin(KID_RANK_SORT, st);
-        SHP_HIP(hipMemsetAsync(pr->rank, 0, (size_t)2 * L * n * 4, st));
-        hipLaunchKernelGGL(rank_count_kernel, dim3(ceil_div(u, 256), 2 * L, ceil_div(u, RANK_SLICE)), dim3(256), 0, st,
-                           pr->sort_raw, pr->rank, u, (size_t)n);
-        hipLaunchKernelGGL(rank_scatter_kernel, dim3(ceil_div(u, 256), 2 * L), dim3(256), 0, st, pr->sort_raw, pr->rank,
-                           pr->sort_out, u, (size_t)n);
+        SHP_REQUIRE(2 * L <= pr->sc_cnt, SHP_ERR_INVALID_ARG, "prove: too many lookups for the sort scratch");
+        hipLaunchKernelGGL(sort_tiles_kernel, dim3(ceil_div(u, SORT_TILE), 2 * L), dim3(512), 0, st, pr->sort_raw, pr->sc_pre,
+                           pr->rank, u, (size_t)n);
+        uint32_t G = 1;
+        while (G < ceil_div(u, SORT_TILE)) G <<= 1;                       // <= 64 for k <= 16
+        hipLaunchKernelGGL(rank_from_tiles_kernel, dim3(ceil_div((size_t)u * G, 256), 2 * L), dim3(256), 0, st, pr->sort_raw,
+                           pr->sc_pre, pr->rank, pr->sort_out, u, (size_t)n, G);
         pr->timers.end(st);
         hb.clear();
         for (uint32_t l = 0; l < L; l++) {

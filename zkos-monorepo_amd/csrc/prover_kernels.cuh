@@ -318,38 +318,93 @@ __global__ void to_raw_kernel(const Fr* in, Fr* out, uint32_t count) {
     if (i < count) st(out + i, ld(in + i).to_raw());
 }
 
-// rank sort, spread over the chip: blockIdx.x = tile of 256 elements, blockIdx.y = array,
-// blockIdx.z = slice of the comparison range; partial ranks meet in `rank` (zeroed by the caller)
-constexpr uint32_t RANK_SLICE = 256;
-__global__ __launch_bounds__(256) void rank_count_kernel(const Fr* raw, uint32_t* rank, uint32_t u, size_t stride) {
-    __shared__ Fr tile[256];
+// Stable sort of the usable rows by (value, row): tiles of 1024 elements are sorted in LDS (bitonic,
+// [limb][element] layout), then every element finds its rank as the sum over the tiles of a binary
+// search (10 steps per tile) -- 80 comparisons per element where the all-pairs rank sort needed 8192
+// (that kernel was 10 % of the prover's vector instructions).
+constexpr uint32_t SORT_TILE = 1024;
+
+// (a, ia) < (b, ib) for raw 256-bit values with the row index as tie break
+__device__ __forceinline__ bool key_less(const Fr& a, uint32_t ia, const Fr& b, uint32_t ib) {
+    return raw_less(a, b) || (!raw_less(b, a) && ia < ib);
+}
+
+// blockIdx.x = tile, blockIdx.y = array; 512 threads, one compare-exchange each per step
+__global__ __launch_bounds__(512) void sort_tiles_kernel(const Fr* raw, Fr* tile_sorted, uint32_t* tile_idx, uint32_t u, size_t stride) {
+    __shared__ uint32_t val[8][SORT_TILE];
+    __shared__ uint32_t idx[SORT_TILE];
+    const uint32_t t = threadIdx.x, base = blockIdx.x * SORT_TILE;
     const Fr* src = raw + (size_t)blockIdx.y * stride;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const Fr mine = i < u ? ld(src + i) : Fr::zero();
-    const uint32_t s0 = blockIdx.z * RANK_SLICE;
-    const uint32_t s1 = s0 + RANK_SLICE < u ? s0 + RANK_SLICE : u;
-    uint32_t r = 0;
-    for (uint32_t base = s0; base < s1; base += 256) {
-        const uint32_t j = base + threadIdx.x;
-        __syncthreads();
-        if (j < s1) tile[threadIdx.x] = ld(src + j);
-        __syncthreads();
-        const uint32_t lim = s1 - base < 256 ? s1 - base : 256;
-        // element j precedes mine iff (x_j, j) < (mine, i): x_j < mine, or not (mine < x_j) and j < i
-        for (uint32_t k = 0; k < lim; k++) {
-            const Fr x = tile[k];
-            const bool before = base + k < i ? !raw_less(mine, x) : raw_less(x, mine);
-            r += before ? 1u : 0u;
+    for (uint32_t e = t; e < SORT_TILE; e += 512) {
+        const uint32_t i = base + e;
+        Fr v;
+        if (i < u) v = ld(src + i);
+        else {
+#pragma unroll
+            for (int l = 0; l < 8; l++) v.l[l] = 0xffffffffu;          // padding sorts to the end
+        }
+#pragma unroll
+        for (int l = 0; l < 8; l++) val[l][e] = v.l[l];
+        idx[e] = i < u ? i : 0xffffffffu;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= SORT_TILE; k <<= 1) {
+        for (uint32_t j = k >> 1; j >= 1; j >>= 1) {
+            const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // element without bit j
+            const uint32_t hi = lo | j;
+            const bool asc = (lo & k) == 0;
+            Fr a, b;
+#pragma unroll
+            for (int l = 0; l < 8; l++) { a.l[l] = val[l][lo]; b.l[l] = val[l][hi]; }
+            const uint32_t ia = idx[lo], ib = idx[hi];
+            const bool swap = asc ? key_less(b, ib, a, ia) : key_less(a, ia, b, ib);
+            if (swap) {
+#pragma unroll
+                for (int l = 0; l < 8; l++) { val[l][lo] = b.l[l]; val[l][hi] = a.l[l]; }
+                idx[lo] = ib;
+                idx[hi] = ia;
+            }
+            __syncthreads();
         }
     }
-    if (i < u && r) atomicAdd(rank + (size_t)blockIdx.y * stride + i, r);
+    Fr* dst = tile_sorted + (size_t)blockIdx.y * stride;
+    uint32_t* di = tile_idx + (size_t)blockIdx.y * stride;
+    for (uint32_t e = t; e < SORT_TILE; e += 512) {
+        const uint32_t i = base + e;
+        if (i < u) {
+            Fr v;
+#pragma unroll
+            for (int l = 0; l < 8; l++) v.l[l] = val[l][e];
+            st(dst + i, v);
+            di[i] = idx[e];
+        }
+    }
 }
-// sorted[rank(i)] = raw[i]
-__global__ void rank_scatter_kernel(const Fr* raw, const uint32_t* rank, Fr* sorted, uint32_t u, size_t stride) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= u) return;
+
+// sorted[rank(i)] = raw[i], rank(i) = number of (value, row) keys below (raw[i], i) over all sorted tiles.
+// G = 2^g >= number of tiles consecutive lanes share one element, one tile each (ten dependent loads
+// instead of eighty), and add their counts with a shuffle butterfly.
+__global__ __launch_bounds__(256) void rank_from_tiles_kernel(const Fr* raw, const Fr* tile_sorted, const uint32_t* tile_idx,
+                                                              Fr* sorted, uint32_t u, size_t stride, uint32_t G) {
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = tid / G, tile = tid % G;
     const size_t o = (size_t)blockIdx.y * stride;
-    st(sorted + o + rank[o + i], ld(raw + o + i));
+    const uint32_t base = tile * SORT_TILE;
+    uint32_t lo = 0;
+    Fr x = Fr::zero();
+    if (i < u) {
+        x = ld(raw + o + i);
+        if (base < u) {
+            uint32_t hi = u - base < SORT_TILE ? u - base : SORT_TILE;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (key_less(ld(tile_sorted + o + base + mid), tile_idx[o + base + mid], x, i)) lo = mid + 1;
+                else hi = mid;
+            }
+        }
+    }
+    for (uint32_t m = G >> 1; m >= 1; m >>= 1) lo += __shfl_xor(lo, (int)m);
+    if (i < u && tile == 0) st(sorted + o + lo, x);
 }
 
 __device__ __forceinline__ bool bsearch_raw(const Fr* arr, uint32_t count, const Fr& key) {
