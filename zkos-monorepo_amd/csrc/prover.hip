@@ -23,6 +23,51 @@
 
 using namespace shp;
 
+namespace {
+struct PolyKey {
+    int kind;       // 0 adv, 1 pz, 2 lz, 3 lpi, 4 lpt, 5 fix, 6 sig, 7 h, 8 rand
+    uint32_t idx;
+    bool operator<(const PolyKey& o) const { return kind != o.kind ? kind < o.kind : idx < o.idx; }
+    bool operator==(const PolyKey& o) const { return kind == o.kind && idx == o.idx; }
+};
+struct RotSet {
+    std::vector<int32_t> rots;          // sorted
+    std::vector<PolyKey> polys;
+};
+}  // namespace
+
+// the verifier's query order (pcs.rs:60-104) grouped into rotation sets (bdfg21.rs:443-494)
+static void build_rotation_sets(const PlanData& P, std::vector<int32_t>& superset, std::vector<RotSet>& sets) {
+    std::vector<std::pair<PolyKey, int32_t>> qs;
+    const uint32_t S = P.num_sets, L = (uint32_t)P.lookups.size();
+    for (auto& q : P.adv_q) qs.push_back({{0, q.col}, q.rot});
+    for (uint32_t s = 0; s < S; s++) { qs.push_back({{1, s}, 0}); qs.push_back({{1, s}, 1}); }
+    for (int s = (int)S - 2; s >= 0; s--) qs.push_back({{1, (uint32_t)s}, P.rot_last});
+    for (uint32_t l = 0; l < L; l++) {
+        qs.push_back({{2, l}, 0}); qs.push_back({{3, l}, 0}); qs.push_back({{4, l}, 0});
+        qs.push_back({{3, l}, -1}); qs.push_back({{2, l}, 1});
+    }
+    for (auto& q : P.fix_q) qs.push_back({{5, q.col}, q.rot});
+    for (uint32_t i = 0; i < P.perm_cols.size(); i++) qs.push_back({{6, i}, 0});
+    qs.push_back({{7, 0}, 0});
+    qs.push_back({{8, 0}, 0});
+    std::vector<std::pair<PolyKey, std::vector<int32_t>>> polys;
+    for (auto& q : qs) {
+        if (std::find(superset.begin(), superset.end(), q.second) == superset.end()) superset.push_back(q.second);
+        auto it = std::find_if(polys.begin(), polys.end(), [&](auto& e) { return e.first == q.first; });
+        if (it == polys.end()) polys.push_back({q.first, {q.second}});
+        else it->second.push_back(q.second);
+    }
+    std::sort(superset.begin(), superset.end());
+    for (auto& pe : polys) {
+        std::vector<int32_t> rs = pe.second;
+        std::sort(rs.begin(), rs.end());
+        auto it = std::find_if(sets.begin(), sets.end(), [&](RotSet& s) { return s.rots == rs; });
+        if (it == sets.end()) sets.push_back({rs, {pe.first}});
+        else it->polys.push_back(pe.first);
+    }
+}
+
 // ------------------------------------------------------------------------------ proving key
 struct shp_pk {
     shp_ctx* ctx = nullptr;
@@ -43,6 +88,8 @@ struct shp_pk {
     std::vector<uint8_t> plan_bytes;               // the circuit plan the key was generated from (shp_pk_save)
     Fr omega, omega_inv, delta, zeta;
     std::vector<Fr> delta_pow;
+    std::vector<int32_t> rot_superset;             // SHPLONK rotation sets of the plan (fixed per key)
+    std::vector<RotSet> rot_sets;
     std::vector<void*> owned;
 
     template <class T>
@@ -204,6 +251,9 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
         raw.l[i] = ((uint32_t)h[31 - 4 * i]) | ((uint32_t)h[30 - 4 * i] << 8) | ((uint32_t)h[29 - 4 * i] << 16) |
                    ((uint32_t)h[28 - 4 * i] << 24);
     to_be32(Fr::from_raw(raw), pk->vk_digest);
+    build_rotation_sets(P, pk->rot_superset, pk->rot_sets);
+    SHP_REQUIRE(pk->rot_superset.size() <= MAX_POINTS && pk->rot_sets.size() <= MAX_SETS, SHP_ERR_INVALID_ARG,
+                "keygen: too many rotation sets");
     *out = pk.release();
 }
 
@@ -555,58 +605,16 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
 }
 
 // ------------------------------------------------------------------------------ host pieces
-namespace {
-struct PolyKey {
-    int kind;       // 0 adv, 1 pz, 2 lz, 3 lpi, 4 lpt, 5 fix, 6 sig, 7 h, 8 rand
-    uint32_t idx;
-    bool operator<(const PolyKey& o) const { return kind != o.kind ? kind < o.kind : idx < o.idx; }
-    bool operator==(const PolyKey& o) const { return kind == o.kind && idx == o.idx; }
-};
-struct RotSet {
-    std::vector<int32_t> rots;          // sorted
-    std::vector<PolyKey> polys;
-};
-}  // namespace
-
-// the verifier's query order (pcs.rs:60-104) grouped into rotation sets (bdfg21.rs:443-494)
-static void build_rotation_sets(const PlanData& P, std::vector<int32_t>& superset, std::vector<RotSet>& sets) {
-    std::vector<std::pair<PolyKey, int32_t>> qs;
-    const uint32_t S = P.num_sets, L = (uint32_t)P.lookups.size();
-    for (auto& q : P.adv_q) qs.push_back({{0, q.col}, q.rot});
-    for (uint32_t s = 0; s < S; s++) { qs.push_back({{1, s}, 0}); qs.push_back({{1, s}, 1}); }
-    for (int s = (int)S - 2; s >= 0; s--) qs.push_back({{1, (uint32_t)s}, P.rot_last});
-    for (uint32_t l = 0; l < L; l++) {
-        qs.push_back({{2, l}, 0}); qs.push_back({{3, l}, 0}); qs.push_back({{4, l}, 0});
-        qs.push_back({{3, l}, -1}); qs.push_back({{2, l}, 1});
-    }
-    for (auto& q : P.fix_q) qs.push_back({{5, q.col}, q.rot});
-    for (uint32_t i = 0; i < P.perm_cols.size(); i++) qs.push_back({{6, i}, 0});
-    qs.push_back({{7, 0}, 0});
-    qs.push_back({{8, 0}, 0});
-    std::vector<std::pair<PolyKey, std::vector<int32_t>>> polys;
-    for (auto& q : qs) {
-        if (std::find(superset.begin(), superset.end(), q.second) == superset.end()) superset.push_back(q.second);
-        auto it = std::find_if(polys.begin(), polys.end(), [&](auto& e) { return e.first == q.first; });
-        if (it == polys.end()) polys.push_back({q.first, {q.second}});
-        else it->second.push_back(q.second);
-    }
-    std::sort(superset.begin(), superset.end());
-    for (auto& pe : polys) {
-        std::vector<int32_t> rs = pe.second;
-        std::sort(rs.begin(), rs.end());
-        auto it = std::find_if(sets.begin(), sets.end(), [&](RotSet& s) { return s.rots == rs; });
-        if (it == sets.end()) sets.push_back({rs, {pe.first}});
-        else it->polys.push_back(pe.first);
-    }
-}
-
 // coefficients (low to high) of the polynomial through (xs, ys)
 static std::vector<Fr> interpolate(const std::vector<Fr>& xs, const std::vector<Fr>& ys) {
     size_t m = xs.size();
     std::vector<Fr> out(m, Fr::zero());
+    std::vector<std::vector<Fr>> nums(m);
+    std::vector<Fr> den(m), pre(m);
+    Fr acc = Fr::one();
     for (size_t i = 0; i < m; i++) {
         std::vector<Fr> num(1, Fr::one());
-        Fr den = Fr::one();
+        Fr d = Fr::one();
         for (size_t j = 0; j < m; j++) {
             if (i == j) continue;
             std::vector<Fr> nx(num.size() + 1, Fr::zero());
@@ -615,10 +623,18 @@ static std::vector<Fr> interpolate(const std::vector<Fr>& xs, const std::vector<
                 nx[t] = nx[t] - xs[j] * num[t];
             }
             num.swap(nx);
-            den = den * (xs[i] - xs[j]);
+            d = d * (xs[i] - xs[j]);
         }
-        Fr sc = ys[i] * Fr::inv(den);
-        for (size_t t = 0; t < m; t++) out[t] = out[t] + sc * num[t];
+        nums[i].swap(num);
+        den[i] = d;
+        pre[i] = acc;
+        acc = acc * d;
+    }
+    Fr inv = Fr::inv(acc);                    // one inversion for the m denominators (distinct points: acc != 0)
+    for (size_t i = m; i-- > 0;) {
+        Fr sc = ys[i] * (inv * pre[i]);
+        inv = inv * den[i];
+        for (size_t t = 0; t < m; t++) out[t] = out[t] + sc * nums[i][t];
     }
     return out;
 }
@@ -884,10 +900,8 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     pc.mark("quotient_msm");
     // ---- P11: evaluations
     const Fr x = tr.squeeze();
-    std::vector<int32_t> superset;
-    std::vector<RotSet> sets;
-    build_rotation_sets(P, superset, sets);
-    SHP_REQUIRE(superset.size() <= MAX_POINTS && sets.size() <= MAX_SETS, SHP_ERR_INVALID_ARG, "prove: too many rotation sets");
+    const std::vector<int32_t>& superset = pk->rot_superset;      // fixed per key (keygen)
+    const std::vector<RotSet>& sets = pk->rot_sets;
     std::map<int32_t, uint32_t> pt_index;
     std::vector<Fr> points(superset.size());
     for (size_t i = 0; i < superset.size(); i++) {
@@ -975,7 +989,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     std::vector<std::vector<Fr>> rcoefs(sets.size());
     Fr nu_pow = Fr::one();
     for (size_t i = 0; i < sets.size(); i++) {
-        RotSet& rs = sets[i];
+        const RotSet& rs = sets[i];
         SHP_REQUIRE(rs.polys.size() <= MAX_SET_POLYS && rs.rots.size() <= MAX_SET_ROTS, SHP_ERR_INVALID_ARG,
                     "prove: rotation set too large");
         lin[i].count = (uint32_t)rs.polys.size();
