@@ -26,7 +26,7 @@ __device__ __forceinline__ void st(Fr* p, const Fr& v) {
 
 // ------------------------------------------------------------------ expression programs
 // One lane per row.  The plan's three-address program runs over "slots" kept in LDS as
-// [slot][limb][lane] (lane-contiguous dwords: conflict free); the instruction stream is wave
+// [slot][16-byte plane][lane] (lane-contiguous: conflict free); the instruction stream is wave
 // uniform, so the opcode switch never diverges.  OUT folds into acc = acc * mult + value:
 // mult = y for the gate part of the quotient, theta for lookup compression.
 struct ProgArgs {
@@ -48,18 +48,21 @@ struct ProgArgs {
 constexpr int PROG_THREADS = 64;
 
 __global__ __launch_bounds__(PROG_THREADS) void prog_fold_kernel(ProgArgs a) {
-    extern __shared__ uint32_t slots[];
+    // slots as two 16-byte planes per slot, [slot][plane][lane]: one ds_read_b128 / ds_write_b128 per plane,
+    // lane-contiguous (conflict free) -- a quarter of the LDS instructions of a [slot][limb][lane] layout
+    extern __shared__ uint4 slots[];
     const uint32_t tid = threadIdx.x;
     const uint32_t row = blockIdx.x * PROG_THREADS + tid;
     auto get = [&](uint32_t s) {
+        const uint4 a0 = slots[(s * 2) * PROG_THREADS + tid], a1 = slots[(s * 2 + 1) * PROG_THREADS + tid];
         Fr v;
-#pragma unroll
-        for (int l = 0; l < 8; l++) v.l[l] = slots[(s * 8 + l) * PROG_THREADS + tid];
+        v.l[0] = a0.x; v.l[1] = a0.y; v.l[2] = a0.z; v.l[3] = a0.w;
+        v.l[4] = a1.x; v.l[5] = a1.y; v.l[6] = a1.z; v.l[7] = a1.w;
         return v;
     };
     auto put = [&](uint32_t s, const Fr& v) {
-#pragma unroll
-        for (int l = 0; l < 8; l++) slots[(s * 8 + l) * PROG_THREADS + tid] = v.l[l];
+        slots[(s * 2) * PROG_THREADS + tid] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+        slots[(s * 2 + 1) * PROG_THREADS + tid] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
     };
     Fr acc = a.acc_in ? ld(a.acc_in + row) : Fr::zero();
     for (uint32_t i = 0; i < a.n_instr; i++) {
