@@ -80,14 +80,21 @@ class _Compiler:
     def compile(self, outputs):
         order, ids = [], {}
 
+        LEAVES = ("const", "adv", "fix", "inst")
+
         def visit(e):
+            # Leaves are re-materialised at every use instead of being kept alive across gates: a load
+            # costs one L2-resident read, a live slot costs 2 KB of LDS per wave -- with every shared
+            # column value pinned the withdraw gates needed 30 slots = 60 KB, i.e. two waves per CU.
             k = id(e)
-            if k in ids:
+            if e.kind not in LEAVES and k in ids:
                 return ids[k]
             kids = [visit(a) for a in e.args if isinstance(a, Expr)]
-            ids[k] = len(order)
+            nid = len(order)
+            if e.kind not in LEAVES:
+                ids[k] = nid
             order.append((e, kids))
-            return ids[k]
+            return nid
 
         out_ids = [visit(e) for e in outputs]
         # sequence: nodes in topological order with OUT markers right after the node is available
