@@ -467,8 +467,9 @@ __device__ __forceinline__ G1Affine load_affine(const G1Affine* p) {
 // intermediates travel between the four lanes through LDS.  Identity operands are selected
 // around; the doubling / opposite-point cases (pp == 0) are rare and redone by lane 0 of the quad
 // with the generic g1_add.
-constexpr uint32_t COOP_POINT_WORDS = 32 * MSM_THREADS;       // [4 coords][8 limbs][256 slots]
-constexpr uint32_t COOP_SCR_WORDS = 12 * 8 * 64;              // [12 values][8 limbs][64 quads]
+constexpr uint32_t COOP_SLOTS = 128;                          // points alive after the first level
+constexpr uint32_t COOP_POINT_WORDS = 32 * COOP_SLOTS;        // [4 coords][8 limbs][128 slots]
+constexpr uint32_t COOP_SCR_WORDS = 9 * 8 * 64;               // [9 values][8 limbs][64 quads]
 constexpr uint32_t COOP_LDS_WORDS = COOP_POINT_WORDS + COOP_SCR_WORDS + 64;
 
 __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_WORDS] */) {
@@ -478,12 +479,12 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
     auto ldc = [&](uint32_t coord, uint32_t slot) {
         Fq v;
 #pragma unroll
-        for (int i = 0; i < 8; i++) v.l[i] = sh[(coord * 8 + i) * MSM_THREADS + slot];
+        for (int i = 0; i < 8; i++) v.l[i] = sh[(coord * 8 + i) * COOP_SLOTS + slot];
         return v;
     };
     auto stc = [&](uint32_t coord, uint32_t slot, const Fq& v) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) sh[(coord * 8 + i) * MSM_THREADS + slot] = v.l[i];
+        for (int i = 0; i < 8; i++) sh[(coord * 8 + i) * COOP_SLOTS + slot] = v.l[i];
     };
     auto lds = [&](uint32_t val, uint32_t quad) {
         Fq v;
@@ -501,15 +502,15 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
         p.x = ldc(0, slot); p.y = ldc(1, slot); p.zz = ldc(2, slot); p.zzz = ldc(3, slot);
         return p;
     };
-    // level 256 -> 128: one addition per lane
-    if (t >= 128) put(t, acc);
+    // level 256 -> 128: one addition per lane (the upper half parks its points in the 128 slots)
+    if (t >= 128) put(t - 128, acc);
     __syncthreads();
     if (t < 128) {
-        acc = g1_add(acc, get(t + 128));
-        put(t, acc);
+        acc = g1_add(acc, get(t));
+        put(t, acc);                      // slot t is read and rewritten by thread t only
     }
     __syncthreads();
-    enum { V_U1 = 0, V_S1, V_U2, V_S2, V_PPU, V_PP, V_RR, V_RR2, V_ZZ12, V_ZZZ12, V_PPP, V_QQ };
+    enum { V_U1 = 0, V_S1, V_U2, V_S2, V_PPU, V_PP, V_RR, V_RR2, V_PPP };
     const uint32_t q = t >> 2, j = t & 3;
     for (uint32_t m = 64; m >= 1; m >>= 1) {
         const bool act = t < 4 * m;
@@ -615,18 +616,34 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
                 cy >>= 32;
             }
             const uint32_t half = a.NB;
-            for (uint32_t w = w0; w < w1; w++) {
-                uint32_t d = raw_bits(raw, w * a.c, a.c);
-                uint32_t neg = 0;
-                if (w + 1 < a.W) {
-                    neg = d < half;
-                    d = neg ? half - d : d - half;
+            // next non-zero digit at or after window w: (table slot, sign), slot == NB means none
+            auto next_digit = [&](uint32_t& w, uint32_t& neg) -> size_t {
+                for (; w < w1; w++) {
+                    uint32_t d = raw_bits(raw, w * a.c, a.c);
+                    neg = 0;
+                    if (w + 1 < a.W) {
+                        neg = d < half;
+                        d = neg ? half - d : d - half;
+                    }
+                    if (d) return ((size_t)w * a.n_table + i) * a.NB + (d - 1);
                 }
-                if (d == 0) continue;
-                const G1Affine p = load_affine(mult + ((size_t)w * a.n_table + i) * a.NB + (d - 1));
-                if (p.is_inf()) continue;
-                const Fq y = neg ? Fq::neg(p.y) : p.y;
-                acc = g1_madd(acc, p.x, y);
+                return (size_t)-1;
+            };
+            // the gather of entry k+1 is in flight while entry k is added (one 64 B random HBM read per
+            // digit: ~2 us exposed per addition otherwise, with only a few waves per SIMD to hide it)
+            uint32_t w = w0, neg = 0;
+            size_t slot = next_digit(w, neg);
+            G1Affine p;
+            if (slot != (size_t)-1) p = load_affine(mult + slot);
+            while (slot != (size_t)-1) {
+                const G1Affine cur = p;
+                const uint32_t cur_neg = neg;
+                w++;
+                slot = next_digit(w, neg);
+                if (slot != (size_t)-1) p = load_affine(mult + slot);
+                if (cur.is_inf()) continue;
+                const Fq y = cur_neg ? Fq::neg(cur.y) : cur.y;
+                acc = g1_madd(acc, cur.x, y);
             }
         }
     }
