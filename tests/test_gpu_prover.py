@@ -267,3 +267,34 @@ def test_witness_schedule_threads_give_identical_proofs(shp, oracle, gpu_ctx, sm
         for _ in range(3):
             assert pr.prove(wit, bytes([5]) * 32) == want, f"{threads} witness threads"
     pr.close(); pk.close(); params.close()
+
+
+def test_pool_queue_bound_and_argument_errors(shp, oracle, gpu_ctx):
+    """bounded queue (the reference's task pool answers 504 when it is full): SHP_ERR_BUSY, then the pool drains;
+    wrong witness length -> SHP_ERR_INVALID_ARG"""
+    PL, C, plan, lay, osrs, opk, params, pk = setup(shp, oracle, gpu_ctx, True)
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    wit = C.withdraw_witness_inputs(lay, H, random.Random(2), 2**31 + 7, 2**20 + 9)
+    blob = b"".join(int(x).to_bytes(32, "little") for x in wit)
+    pool = shp.Pool(pk, 1, queue_cap=1)
+    tickets, busy = [], 0
+    for i in range(6):
+        try:
+            tickets.append(pool.submit(blob, bytes([i + 1]) * 32))
+        except shp.ShpError as e:
+            assert e.code == 7
+            busy += 1
+    assert busy >= 1 and len(tickets) >= 2
+    for t in tickets:
+        proof, inst = pool.wait(t)
+        assert PL.verify(opk, proof, inst, tau=TAU)
+    with pytest.raises(shp.ShpError) as e:
+        pool.submit(blob[:-32], bytes(32))
+    assert e.value.code == 1
+    with pytest.raises(shp.ShpError):
+        pool.wait(10**9)                            # unknown ticket
+    single = shp.Prover(pk)
+    with pytest.raises(shp.ShpError) as e:
+        single.prove_bytes(blob + bytes(32), bytes(32))
+    assert e.value.code == 1
+    single.close(); pool.close(); pk.close(); params.close()

@@ -81,6 +81,11 @@ struct shp_msm {
     shp::Fr bias;                         // signed-digit bias of the direct mode
     shp::MsmWorkspace ws;
     std::mutex mu;
+    ~shp_msm() {                          // also runs when plan construction throws half way
+        if (d_table) (void)hipFree(d_table);
+        if (d_mult) (void)hipFree(d_mult);
+        ws.release();
+    }
 };
 
 struct shp_srs {

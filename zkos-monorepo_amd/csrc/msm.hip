@@ -949,11 +949,7 @@ int32_t shp_msm_create(shp_ctx* ctx, const void* h_bases, size_t n, uint32_t win
 
 int32_t shp_msm_destroy(shp_msm* m) {
     return guarded([&] {
-        if (!m) return;
-        if (m->d_table) (void)hipFree(m->d_table);
-        if (m->d_mult) (void)hipFree(m->d_mult);
-        m->ws.release();
-        delete m;
+        delete m;                         // ~shp_msm frees the tables and the workspace
     });
 }
 

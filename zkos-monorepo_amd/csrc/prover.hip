@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "prover_kernels.cuh"
@@ -112,11 +113,10 @@ struct shp_pk {
 
 static void launch_prog(hipStream_t st, const ProgArgs& a, uint32_t size) {
     size_t lds = (size_t)a.nslots * 8 * PROG_THREADS * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SHP_HIP(hipFuncSetAttribute((const void*)prog_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 8 * PROG_THREADS * 4));
-        attr_set = true;
-    }
+    static std::once_flag attr_once;       // lanes launch from several host threads
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute((const void*)prog_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 8 * PROG_THREADS * 4);
+    });
     hipLaunchKernelGGL(prog_fold_kernel, dim3(size / PROG_THREADS), dim3(PROG_THREADS), lds, st, a);
 }
 
