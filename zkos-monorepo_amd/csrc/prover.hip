@@ -132,7 +132,7 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     PlanData& P = pk->plan;
     P.parse(plan_bytes, len);
     SHP_REQUIRE(P.k == srs->k, SHP_ERR_INVALID_ARG, "keygen: plan k differs from the SRS k");
-    SHP_REQUIRE(P.n >= 64 && P.k <= 16 && P.perm_cols.size() <= MAX_PERM_COLS && P.num_sets >= 1, SHP_ERR_INVALID_ARG,
+    SHP_REQUIRE(P.n >= 64 && P.k <= 16 && P.perm_cols.size() <= MAX_PERM_COLS, SHP_ERR_INVALID_ARG,
                 "keygen: unsupported plan shape");
     keccak256(plan_bytes, len, P.plan_hash);
     const uint32_t n = P.n, k = P.k, ek = P.ext_k, ne = 1u << ek;
@@ -228,7 +228,7 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
         std::copy(stored_comm->begin() + F, stored_comm->end(), pk->sigma_comm.begin());
     } else {
         if (F) msm_run(srs->msm_gl, pk->fixed_vals, n, n, F, pk->fixed_comm.data(), st);
-        msm_run(srs->msm_gl, pk->sigma_vals, n, n, PC, pk->sigma_comm.data(), st);
+        if (PC) msm_run(srs->msm_gl, pk->sigma_vals, n, n, PC, pk->sigma_comm.data(), st);
     }
     SHP_HIP(hipStreamSynchronize(st));
     // vk digest: keccak("shielder-hip-vk-v1" | keccak(plan) | commitments) mod r
@@ -820,7 +820,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         pg.col[c] = t == COL_ADVICE ? V(ix) : t == COL_FIXED ? pk->fixed_vals + (size_t)ix * n : V(I_INST);
         pg.dbeta[c] = pk->delta_pow[c] * beta;
     }
-    hipLaunchKernelGGL(perm_ratio_kernel, dim3(ceil_div(n, 256), S), dim3(256), 0, st, pg, n, pr->num, pr->den);
+    if (S) hipLaunchKernelGGL(perm_ratio_kernel, dim3(ceil_div(n, 256), S), dim3(256), 0, st, pg, n, pr->num, pr->den);
     if (L)
         hipLaunchKernelGGL(lookup_ratio_kernel, dim3(ceil_div(n, 256), L), dim3(256), 0, st, pr->cin, pr->ctab, V(I_PIN),
                            V(I_PIN + 1), (size_t)2 * n, n, beta, gamma, pr->num + (size_t)S * n, pr->den + (size_t)S * n);
@@ -829,16 +829,18 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         for (uint32_t j = 0; j < bf; j++) hb.push_back(draw());
         ctr += 1;
     }
-    SHP_HIP(hipMemcpyAsync(pr->blinds, hb.data(), hb.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
+    if (!hb.empty()) SHP_HIP(hipMemcpyAsync(pr->blinds, hb.data(), hb.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
     pr->timers.begin(KID_GRAND_PRODUCT, st);
-    product_scans(pr->num, pr->den, S + L);
-    hipLaunchKernelGGL(grand_product_apply_kernel, dim3(snb, S + L), dim3(sbs), 0, st, pr->sc_pre, pr->sc_suf, sc_bpre, sc_bsuf,
-                       sc_inv, n, S, u, bf, V(I_PZ), (size_t)n, pr->blinds);
+    if (S + L) {                                           // a plan may have neither a permutation nor a lookup
+        product_scans(pr->num, pr->den, S + L);
+        hipLaunchKernelGGL(grand_product_apply_kernel, dim3(snb, S + L), dim3(sbs), 0, st, pr->sc_pre, pr->sc_suf, sc_bpre,
+                           sc_bsuf, sc_inv, n, S, u, bf, V(I_PZ), (size_t)n, pr->blinds);
+    }
     pr->timers.end(st);
     SHP_REQUIRE(ctr == ctr_rand, SHP_ERR_INTERNAL, "prove: blinding stream position of the random polynomial");
     ctr += n;
     ctr += 1;
-    msm_run_ws(srs->msm_gl, pr->msm_ws, V(I_PZ), n, n, S + L, pts.data(), st);
+    if (S + L) msm_run_ws(srs->msm_gl, pr->msm_ws, V(I_PZ), n, n, S + L, pts.data(), st);
     for (uint32_t i = 0; i < S + L; i++) tr.write_point(pts[i].x, pts[i].y);
     tr.write_point(rand_comm.x, rand_comm.y);
     pc.mark("products_msm");
@@ -852,6 +854,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     ntt_launch(ctx, pr->vals, pr->polys, k, NV + 1, inv, st, pr->ntt_tmp);
     ntt_launch(ctx, pr->polys, pr->cos, ek, NV + 1, ext, st, pr->ntt_tmp);
     // ---- P10: quotient
+    const uint32_t ebs = std::min<uint32_t>(256, ne);     // element-wise kernels over the extended domain (ne >= 128)
     extended_domain(pa);
     pa.mult = y; pa.acc_in = nullptr;
     pa.prog = pk->gate_prog; pa.n_instr = (uint32_t)P.gate_prog.size(); pa.nslots = P.gate_slots;
@@ -859,7 +862,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     pr->timers.begin(KID_PROG, st);
     launch_prog(st, pa, ne);
     pr->timers.end(st);
-    {
+    if (S) {
         PermQArgs q;
         q.p = pg;
         q.p.sigma = pk->sigma_cos; q.p.sigma_stride = ne; q.p.xs = pk->x_ext;
@@ -870,7 +873,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         q.pz = CS(I_PZ);
         q.l0 = pk->l0; q.l_last = pk->l_last; q.l_active = pk->l_active;
         q.n_sets = S; q.mask = ne - 1; q.step = estep; q.rot_last = P.rot_last; q.y = y; q.h = pr->h;
-        hipLaunchKernelGGL(perm_quotient_kernel, dim3(ne / 256), dim3(256), 0, st, q);
+        hipLaunchKernelGGL(perm_quotient_kernel, dim3(ne / ebs), dim3(ebs), 0, st, q);
     }
     for (uint32_t l = 0; l < L; l++) {
         const LookupPlan& lk = P.lookups[l];
@@ -887,9 +890,9 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         q.ain = pr->aux_ext; q.stab = pr->aux_ext + ne;
         q.l0 = pk->l0; q.l_last = pk->l_last; q.l_active = pk->l_active;
         q.mask = ne - 1; q.step = estep; q.y = y; q.beta = beta; q.gamma = gamma; q.h = pr->h;
-        hipLaunchKernelGGL(lookup_quotient_kernel, dim3(ne / 256), dim3(256), 0, st, q);
+        hipLaunchKernelGGL(lookup_quotient_kernel, dim3(ne / ebs), dim3(ebs), 0, st, q);
     }
-    hipLaunchKernelGGL(scale_periodic_kernel, dim3(ne / 256), dim3(256), 0, st, pr->h, pk->t_inv, estep - 1);
+    hipLaunchKernelGGL(scale_periodic_kernel, dim3(ne / ebs), dim3(ebs), 0, st, pr->h, pk->t_inv, estep - 1);
     NttOpts back;
     back.inverse = true; back.post_pattern = 1;
     ntt_launch(ctx, pr->h, pr->h, ek, 1, back, st, pr->ntt_tmp);
@@ -1137,7 +1140,7 @@ int32_t shp_pk_info(const shp_pk* pk, uint32_t* k, uint32_t* n_witness_inputs, u
         const PlanData& P = pk->plan;
         uint32_t L = (uint32_t)P.lookups.size(), S = P.num_sets;
         uint32_t n_points = P.num_advice + 2 * L + S + L + 1 + (P.degree - 1);
-        uint32_t n_evals = (uint32_t)(P.adv_q.size() + P.fix_q.size() + 1 + P.perm_cols.size() + (3 * S - 1) + 5 * L);
+        uint32_t n_evals = (uint32_t)(P.adv_q.size() + P.fix_q.size() + 1 + P.perm_cols.size() + (S ? 3 * S - 1 : 0) + 5 * L);
         if (k) *k = P.k;
         if (n_witness_inputs) *n_witness_inputs = P.n_winputs;
         if (n_instances) *n_instances = P.num_instance;
