@@ -40,12 +40,12 @@ def random_plan(seed):
         r = rnd.random()
         if r < 0.6:
             c, rot = rnd.choice(in_cols), rnd.choice([0, 0, 0, 1, -1, 2])
-            return B.Adv(c, rot), (lambda row, c=c, rot=rot: adv_val[c][(row + rot) % n])
+            return B.Adv(c, rot), (lambda row, c=c, rot=rot: adv_val[c][(row + rot) % n]), ("adv", c, rot)
         if r < 0.85:
             c, rot = rnd.choice(fix), rnd.choice([0, 0, 1])
-            return B.Fix(c, rot), (lambda row, c=c, rot=rot: fv(c, row + rot))
+            return B.Fix(c, rot), (lambda row, c=c, rot=rot: fv(c, row + rot)), ("fix", c, rot)
         v = rnd.randrange(1, 1000)
-        return B.Const(v), (lambda row, v=v: v)
+        return B.Const(v), (lambda row, v=v: v), ("const", v)
 
     def expr(deg):
         if deg <= 1 or rnd.random() < 0.15:
@@ -53,22 +53,22 @@ def random_plan(seed):
         op = rnd.random()
         if op < 0.5:
             d1 = rnd.randint(1, deg - 1)
-            (e1, f1), (e2, f2) = expr(d1), expr(deg - d1)
-            return e1 * e2, (lambda row: f1(row) * f2(row) % R)
-        (e1, f1), (e2, f2) = expr(deg), expr(rnd.randint(1, deg))
+            (e1, f1, t1), (e2, f2, t2) = expr(d1), expr(deg - d1)
+            return e1 * e2, (lambda row: f1(row) * f2(row) % R), ("mul", t1, t2)
+        (e1, f1, t1), (e2, f2, t2) = expr(deg), expr(rnd.randint(1, deg))
         if op < 0.75:
-            return e1 + e2, (lambda row: (f1(row) + f2(row)) % R)
+            return e1 + e2, (lambda row: (f1(row) + f2(row)) % R), ("add", t1, t2)
         if op < 0.95:
-            return e1 - e2, (lambda row: (f1(row) - f2(row)) % R)
-        return -e1, (lambda row: (-f1(row)) % R)
+            return e1 - e2, (lambda row: (f1(row) - f2(row)) % R), ("sub", t1, t2)
+        return -e1, (lambda row: (-f1(row)) % R), ("neg", t1)
 
     max_deg = rnd.choice([1, 2, 3, 4, 6])
     gates = []
     for _ in range(rnd.randint(1, 4)):
         q = b.fixed_column()
-        e, f = expr(rnd.randint(1, max_deg))
+        e, f, tree = expr(rnd.randint(1, max_deg))
         b.gate(B.Fix(q) * (B.Adv(out_col) - e))
-        gates.append((q, f))
+        gates.append((q, f, tree))
     # lookups: tables are fixed columns holding 0..T-1 (every other row is 0, and 0 is in the table)
     n_lk = rnd.choice([0, 1, 1, 2])
     T = 12
@@ -122,14 +122,18 @@ def random_plan(seed):
             adv_val[c][r] = rnd.randrange(T) if c in lookup_cols else (rnd.randrange(R) if rnd.random() < 0.7 else rnd.randrange(3))
     for r in range(usable):
         adv_val[out_col][r] = rnd.randrange(R)
+    computed = {}                                          # rows whose output cell the WITNESS PROGRAM computes
     for r in range(3, usable - 3):                         # rotations -1..2 stay inside the usable rows
         if rnd.random() < 0.5:
-            q, f = gates[r % len(gates)]
+            q, f, tree = gates[r % len(gates)]
             b.fix(q, r, 1)
             fix_val[(q, r)] = 1
             adv_val[out_col][r] = f(r)
+            if rnd.random() < 0.6:
+                computed[r] = tree
     # copies: only between cells that hold equal values, plus the public inputs
     cells = [(t, i) for t, i in eq if t == B.COL_ADVICE]
+    pinned = set()                                         # cells already tied to another by a copy
     for _ in range(rnd.randint(0, 10)):
         if not cells:
             break
@@ -137,17 +141,44 @@ def random_plan(seed):
         ra, rb = rnd.randrange(usable), rnd.randrange(usable)
         if adv_val[ia][ra] == adv_val[ib][rb]:
             b.copy((ta, ia, ra), (tb, ib, rb))
-        elif ia not in lookup_cols and ia != out_col and not any(fix_val.get((q, ra + d), 0) for q, _ in gates for d in (-2, -1, 0, 1)):
+            pinned.update({(ia, ra), (ib, rb)})
+        elif (ia, ra) not in pinned and ia not in lookup_cols and ia != out_col and not any(fix_val.get((q, ra + d), 0) for q, _, _ in gates for d in (-2, -1, 0, 1)):
             adv_val[ia][ra] = adv_val[ib][rb]           # make them equal where no selected gate reads the cell
             b.copy((ta, ia, ra), (tb, ib, rb))
+            pinned.update({(ia, ra), (ib, rb)})
     idx = 0
     values = []
     for c in adv:
         for r in range(usable):
+            if c == out_col and r in computed:
+                continue                                   # filled in by the witness program below
             b.w(B.W_INPUT, (c, r), imm=idx)
             idx += 1
             values.append(adv_val[c][r])
     b.n_winputs = idx
+    # witness program for the computed cells: the gate's expression evaluated through scratch cells that are
+    # re-used from row to row (the lane's witness scheduler has to keep such programs apart)
+    for r, tree in computed.items():
+        nxt = [0]
+
+        def emit(t):
+            if t[0] == "adv":
+                return (t[1], (r + t[2]) % n)
+            sc = b.scratch(nxt[0])
+            nxt[0] += 1
+            if t[0] == "fix":
+                b.w(B.W_CONST, sc, imm=b.const_index(fv(t[1], r + t[2])))
+            elif t[0] == "const":
+                b.w(B.W_CONST, sc, imm=b.const_index(t[1]))
+            elif t[0] == "neg":
+                z = b.scratch(nxt[0]); nxt[0] += 1
+                b.w(B.W_CONST, z, imm=b.const_index(0))
+                b.w(B.W_SUB, sc, z, emit(t[1]))
+            else:
+                x, y = emit(t[1]), emit(t[2])
+                b.w({"mul": B.W_MUL, "add": B.W_ADD, "sub": B.W_SUB}[t[0]], sc, x, y)
+            return sc
+        b.w(B.W_COPY, (out_col, r), emit(tree))
     for i in range(n_inst):
         b.instance_map.append((adv[0], i))
         b.copy((B.COL_ADVICE, adv[0], i), (B.COL_INSTANCE, 0, i))
@@ -172,4 +203,6 @@ def test_random_plan_proof_bytes(shp, oracle, gpu_ctx, seed):
     got = pr.prove(values, seed_bytes)
     assert got[1] == want[1], "public inputs differ"
     assert got[0] == want[0], f"proof bytes differ (k={k}, A={plan.num_advice}, degree={plan.degree}, lookups={len(plan.lookups)})"
+    pr.witness_threads(1 if seed % 2 else 3)             # the sequential program / another task split
+    assert pr.prove(values, seed_bytes) == want
     pr.close(); pk.close(); params.close()
