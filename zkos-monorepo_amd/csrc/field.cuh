@@ -488,13 +488,23 @@ struct alignas(16) Fp {
             : "vcc");
         return mask;
     }
-    __device__ __forceinline__ void raw_shl1() {
+    // multi-bit shifts of the raw 256-bit value, 1 <= t <= 31 (one funnel shift per limb)
+    __device__ __forceinline__ void raw_shr(uint32_t t) {
 #pragma unroll
-        for (int i = 7; i > 0; i--) l[i] = (l[i] << 1) | (l[i - 1] >> 31);
-        l[0] <<= 1;
+        for (int i = 0; i < 7; i++) l[i] = (l[i] >> t) | (l[i + 1] << (32 - t));
+        l[7] >>= t;
     }
-    // Kaliski's almost-inverse (shift / add / subtract only, exactly k <= 2 * 254 iterations, no
-    // modular halving) followed by the 2^k correction as Montgomery products with one-bit constants:
+    __device__ __forceinline__ void raw_shl(uint32_t t) {
+#pragma unroll
+        for (int i = 7; i > 0; i--) l[i] = (l[i] << t) | (l[i - 1] >> (32 - t));
+        l[0] <<= t;
+    }
+    static __device__ __forceinline__ uint32_t tz31(uint32_t low) {      // trailing zeros, capped at 31
+        return low ? (uint32_t)__builtin_ctz(low) : 31u;
+    }
+    // Kaliski's almost-inverse (shift / add / subtract only, no modular halving) with every run of
+    // trailing zero bits shifted out at once (~180 iterations instead of ~370), followed by the 2^k
+    // correction as Montgomery products with one-bit constants:
     // x = (aR)^-1 2^k  ->  x 2^512 (by R^3)  ->  / 2^k1  ->  / 2^k2   (k1 + k2 = k)  =  a^-1 R.
     static __device__ Fp inv_kaliski(const Fp& a) {
         Fp u = modulus(), v = a, r = zero(), s = zero(), d;
@@ -502,23 +512,35 @@ struct alignas(16) Fp {
         uint32_t k = 0;
         while (!v.is_zero() && k < 600) {
             if (!(u.l[0] & 1u)) {
-                u.raw_shr1();
-                s.raw_shl1();
+                const uint32_t t = tz31(u.l[0]);
+                u.raw_shr(t);
+                s.raw_shl(t);
+                k += t;
             } else if (!(v.l[0] & 1u)) {
-                v.raw_shr1();
-                r.raw_shl1();
-            } else if (raw_sub_borrow(d, v, u) == 0) {     // v >= u (u == v == 1 ends the loop here)
+                const uint32_t t = tz31(v.l[0]);
+                v.raw_shr(t);
+                r.raw_shl(t);
+                k += t;
+            } else if (raw_sub_borrow(d, v, u) == 0) {     // v >= u
                 v = d;
-                v.raw_shr1();
                 raw_add_to(s, r);
-                r.raw_shl1();
+                if (v.is_zero()) {                         // u == v == 1: the last step of the plain algorithm
+                    r.raw_shl(1);
+                    k += 1;
+                    break;
+                }
+                const uint32_t t = tz31(v.l[0]);
+                v.raw_shr(t);
+                r.raw_shl(t);
+                k += t;
             } else {
                 raw_sub_borrow(u, u, v);
-                u.raw_shr1();
                 raw_add_to(r, s);
-                s.raw_shl1();
+                const uint32_t t = tz31(u.l[0]);
+                u.raw_shr(t);
+                s.raw_shl(t);
+                k += t;
             }
-            k++;
         }
         if (r.geq_p()) r.raw_sub(modulus());
         Fp x = modulus();

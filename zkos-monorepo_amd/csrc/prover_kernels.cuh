@@ -245,6 +245,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_totals_kernel(const Fr* tot
                                                                    Fr* bsuf_b, Fr* inv_b) {
     __shared__ Fr sh[SCAN_THREADS];
     const uint32_t t = threadIdx.x, p = blockIdx.x;
+    if (nb <= 64) {
+        // the usual case (n <= 2^14): one wave, both scans by shuffles in one pass, no barriers
+        if (t >= 64) return;
+        const Fr xa = t < nb ? ld(tot_a + (size_t)p * nb + t) : Fr::one();
+        const Fr xb = t < nb ? ld(tot_b + (size_t)p * nb + t) : Fr::one();
+        Fr ia = xa, sb = xb;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            Fr ua = shfl_up_fr(ia, off), db = shfl_down_fr(sb, off);
+            if ((int)t >= off) ia = ia * ua;
+            if ((int)t + off < 64) sb = sb * db;
+        }
+        Fr ea = shfl_up_fr(ia, 1), eb = shfl_down_fr(sb, 1);
+        if (t == 0) ea = Fr::one();
+        if (t == 63) eb = Fr::one();
+        if (t < nb) {
+            st(bpre_a + (size_t)p * nb + t, ea);
+            st(bsuf_b + (size_t)p * nb + t, eb);
+        }
+        if (t == 0) st(inv_b + p, Fr::inv(sb));            // lane 0's inclusive suffix = the product of all b
+        return;
+    }
     const Fr va = t < nb ? ld(tot_a + (size_t)p * nb + t) : Fr::one();
     const Fr vb = t < nb ? ld(tot_b + (size_t)p * nb + t) : Fr::one();
     Fr ea = block_scan_fwd_excl(va, sh, t, SCAN_THREADS);
