@@ -472,7 +472,9 @@ constexpr uint32_t COOP_POINT_WORDS = 32 * COOP_SLOTS;        // [4 coords][8 li
 constexpr uint32_t COOP_SCR_WORDS = 9 * 8 * 64;               // [9 values][8 limbs][64 quads]
 constexpr uint32_t COOP_LDS_WORDS = COOP_POINT_WORDS + COOP_SCR_WORDS + 64;
 
-__device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_WORDS] */) {
+// `count` (wave-uniform): threads >= count are known to hold the identity, so the levels that would only
+// add identities are skipped.
+__device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_WORDS] */, uint32_t count = MSM_THREADS) {
     const uint32_t t = threadIdx.x;
     uint32_t* scr = sh + COOP_POINT_WORDS;
     uint32_t* flg = scr + COOP_SCR_WORDS;                       // per quad: bit0 inf1, bit1 inf2, bit2 pp == 0
@@ -503,16 +505,22 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
         return p;
     };
     // level 256 -> 128: one addition per lane (the upper half parks its points in the 128 slots)
-    if (t >= 128) put(t - 128, acc);
-    __syncthreads();
-    if (t < 128) {
-        acc = g1_add(acc, get(t));
-        put(t, acc);                      // slot t is read and rewritten by thread t only
+    if (count > 128) {
+        if (t >= 128) put(t - 128, acc);
+        __syncthreads();
+        if (t < 128) {
+            acc = g1_add(acc, get(t));
+            put(t, acc);                  // slot t is read and rewritten by thread t only
+        }
+    } else if (t < 128) {
+        put(t, acc);
     }
     __syncthreads();
+    uint32_t m0 = 64;
+    while (m0 > 1 && m0 >= count) m0 >>= 1;               // slots >= count hold the identity: nothing to add there
     enum { V_U1 = 0, V_S1, V_U2, V_S2, V_PPU, V_PP, V_RR, V_RR2, V_PPP };
     const uint32_t q = t >> 2, j = t & 3;
-    for (uint32_t m = 64; m >= 1; m >>= 1) {
+    for (uint32_t m = m0; m >= 1; m >>= 1) {
         const bool act = t < 4 * m;
         const uint32_t a = q, b = q + m;
         Fq mine = Fq::zero(), keep = Fq::zero();
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_direct_final_kernel(const G1X
     const G1X* p = partials + (size_t)m * P;
     G1X acc = G1X::inf();
     for (uint32_t j = threadIdx.x; j < P; j += MSM_THREADS) acc = g1_add(acc, p[j]);
-    acc = block_sum_256(acc, sh);
+    acc = block_sum_256(acc, sh, P < MSM_THREADS ? P : MSM_THREADS);
     if (threadIdx.x == 0) out[m] = acc;
 }
 
@@ -790,10 +798,11 @@ static void msm_run_direct(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalar
     const uint32_t gx = ceil_div(n_scalars, MSM_THREADS);
     // T windows per lane: all of them when the launch fills the chip anyway (least tree overhead),
     // shorter chains for small launches (latency)
-    const uint32_t cand[5] = {W, (W + 1) / 2, 8, 4, 2};
-    uint32_t T = 2;
+    static const uint64_t min_waves = getenv("SHP_MSM_MIN_WAVES") ? (uint64_t)atol(getenv("SHP_MSM_MIN_WAVES")) : 1024;
+    const uint32_t cand[6] = {W, (W + 1) / 2, 8, 4, 2, 1};
+    uint32_t T = 1;
     for (uint32_t t : cand)
-        if (t <= W && (uint64_t)gx * (MSM_THREADS / 64) * ceil_div(W, t) * total >= 1024) { T = t; break; }
+        if (t <= W && (uint64_t)gx * (MSM_THREADS / 64) * ceil_div(W, t) * total >= min_waves) { T = t; break; }
     const uint32_t gy = ceil_div(W, T);
     const uint32_t P = gx * gy;
     ws.pf.reserve((size_t)total * P * sizeof(G1X));
