@@ -195,6 +195,13 @@ int32_t shp_prove(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, c
  * permutations of the Merkle levels run side by side).  Default 4 (env SHP_WITNESS_THREADS); a
  * proving pool with more than 4 lanes sets 1 -- throughput does not need it, latency does. */
 int32_t shp_prover_witness_threads(shp_prover* p, uint32_t threads);
+/* shielder_circuits::verify(&params, &vk, &proof, &pub_input)
+ * (/root/reference/crates/shielder_bindings/src/circuits/mod.rs:113-124): the verifier the reference's
+ * generator emits as Solidity (crates/halo2-verifier/templates/Halo2Verifier.sol, pcs/bdfg21.rs), on
+ * the host: transcript replay, quotient identity, SHPLONK, final pairing e(lhs, g2) e(W', -s g2) = 1.
+ * *accepted = 1 / 0; the status is an error only for unusable arguments (e.g. an SRS without G2). */
+int32_t shp_verify(const shp_pk* pk, const uint8_t* proof, size_t proof_len, const uint8_t* instances_le32,
+                   size_t n_instances, int32_t* accepted);
 /* HIP-event timing of the lane's kernel launches, on the stream they run on: enable (resets the
  * counters), prove, then read entry `index` (0 .. until SHP_ERR_INVALID_ARG): kernel family name,
  * number of launches, summed duration. */

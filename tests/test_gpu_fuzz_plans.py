@@ -192,7 +192,7 @@ def test_random_plan_proof_bytes(shp, oracle, gpu_ctx, seed):
     plan = PL.Plan(plan_bytes)
     osrs = oracle.srs_synthetic(k, TAU)
     opk = PL.keygen(plan, osrs)
-    params = shp.Params.from_parts(gpu_ctx, k, osrs.g, osrs.g_lagrange)
+    params = shp.Params.synthetic(gpu_ctx, k, TAU)        # carries the G2 half: the native verifier can run
     pk = shp.ProvingKey(gpu_ctx, params, plan_bytes)
     pr = shp.Prover(pk)
     seed_bytes = bytes([seed]) * 32
@@ -205,4 +205,11 @@ def test_random_plan_proof_bytes(shp, oracle, gpu_ctx, seed):
     assert got[0] == want[0], f"proof bytes differ (k={k}, A={plan.num_advice}, degree={plan.degree}, lookups={len(plan.lookups)})"
     pr.witness_threads(1 if seed % 2 else 3)             # the sequential program / another task split
     assert pr.prove(values, seed_bytes) == want
+    # the library's own verifier (pairing included) on every plan shape
+    assert pk.verify(*got)
+    if want[1]:
+        wrong = list(want[1]); wrong[0] = (wrong[0] + 1) % R
+        assert not pk.verify(got[0], wrong)
+    bad = bytearray(got[0]); bad[(seed * 37) % len(bad)] ^= 1
+    assert not pk.verify(bytes(bad), got[1])
     pr.close(); pk.close(); params.close()

@@ -296,6 +296,14 @@ class ProvingKey:
         _check(lib().shp_pk_save(self.h, out, C.c_size_t(n.value), C.byref(n)))
         return out.raw[:n.value]
 
+    def verify(self, proof: bytes, instances) -> bool:
+        """Circuit::verify (crates/shielder_bindings/src/circuits/mod.rs:113-124): native verifier incl. pairing"""
+        ins = b"".join(int(x).to_bytes(32, "little") for x in instances)
+        ok = C.c_int32(0)
+        _check(lib().shp_verify(self.h, C.c_char_p(proof), C.c_size_t(len(proof)), C.c_char_p(ins), C.c_size_t(len(instances)),
+                                C.byref(ok)))
+        return bool(ok.value)
+
     def vk_digest(self) -> bytes:
         out = C.create_string_buffer(32)
         _check(lib().shp_pk_vk_digest(self.h, out))

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include "engine.hpp"
 #include "hostcrypto.hpp"
+#include "verify.hpp"
 
 namespace shp {
 
@@ -383,7 +384,11 @@ int32_t shp_srs_synthetic(shp_ctx* ctx, uint32_t k, const uint8_t tau_le32[32], 
         (void)hipFree(d_s);
         (void)hipFree(d_g);
         SHP_HIP(e);
-        int32_t rc = shp_srs_from_parts(ctx, k, g.data(), nullptr, nullptr, nullptr, out);
+        // the G2 half of the same SRS (g2 = the standard generator, s_g2 = tau g2), so that proofs over a
+        // synthetic SRS verify through the same pairing as proofs over a ceremony SRS
+        uint8_t g2b[128], sg2b[128];
+        shp_synthetic_g2(tau, g2b, sg2b);
+        int32_t rc = shp_srs_from_parts(ctx, k, g.data(), nullptr, g2b, sg2b, out);
         SHP_REQUIRE(rc == SHP_OK, rc, shp_last_error());
     });
 }

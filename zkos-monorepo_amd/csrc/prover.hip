@@ -21,6 +21,7 @@
 
 #include "prover_kernels.cuh"
 #include "poseidon2.cuh"
+#include "verify.hpp"
 
 using namespace shp;
 
@@ -1062,6 +1063,25 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     proof_out.swap(tr.proof);
     instances_out.swap(instances);
     (void)F;
+}
+
+void shp_pk_vk_view(const shp_pk* pk, VkView& out) {
+    out.plan = &pk->plan;
+    out.vk_digest = pk->vk_digest;
+    out.fixed_comm = &pk->fixed_comm;
+    out.sigma_comm = &pk->sigma_comm;
+    out.omega = pk->omega;
+    out.delta = pk->delta;
+    out.superset = &pk->rot_superset;
+    out.sets.clear();
+    for (const RotSet& rs : pk->rot_sets) {
+        std::vector<std::pair<int, uint32_t>> keys;
+        for (const PolyKey& k : rs.polys) keys.push_back({k.kind, k.idx});
+        out.sets.push_back({rs.rots, keys});
+    }
+    out.g2 = pk->srs->g2;
+    out.s_g2 = pk->srs->s_g2;
+    out.has_g2 = pk->srs->has_g2;
 }
 
 // ------------------------------------------------------------------------------ C ABI

@@ -1,0 +1,513 @@
+// Native verifier: shielder_circuits::verify(&params, &vk, &proof, &pub_input)
+// (/root/reference/crates/shielder_bindings/src/circuits/mod.rs:113-124) for proofs of a circuit plan.
+//
+// Host code only (a verification is a few dozen group operations and one pairing product: ~40 ms on one
+// core, nothing for the GPU to do).  The equations are those the reference's verifier generator
+// emits (/root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:247-559,
+// src/lib/codegen/{util,evaluator,pcs}.rs, pcs/bdfg21.rs; digest in SURVEY.md Appendix C):
+//   1. replay the Keccak transcript over the proof bytes -> theta, beta, gamma, y, x, zeta, nu, mu
+//   2. l_0, l_last, l_blind, instance evaluation at x
+//   3. fold gate / permutation / lookup expressions with y, require h(x) = numer / (x^n - 1)
+//   4. SHPLONK (Bdfg21): per rotation set the barycentric combination of the claimed evaluations and
+//      the zeta-combination of the commitments, then
+//        lhs = sum_i coef_i F_i - r G - Z_0(mu) W + mu W'      and      e(lhs, g2) e(W', -s g2) = 1
+// The pairing is the optimal ate pairing on BN254 (EIP-197's precompile), constants from
+// tools/gen_pairing_constants.py.  The test suite's CPU verifier (Python integers) is an independent
+// restatement; tests compare the two on valid, tampered and wrong-instance proofs.
+#include <string.h>
+
+#include <map>
+
+#include <algorithm>
+#include <tuple>
+
+#include "hostcrypto.hpp"
+#include "verify.hpp"
+#include "pairing_constants.inc"
+
+using namespace shp;
+
+// ------------------------------------------------------------------------------ Fq2 / Fq12 (host)
+namespace {
+
+Fq fq_from_words(const uint32_t w[8]) {
+    Fq r;
+    memcpy(r.l, w, 32);
+    return Fq::from_raw(r);
+}
+
+struct F2 {
+    Fq c0, c1;
+    static F2 zero() { return {Fq::zero(), Fq::zero()}; }
+    static F2 one() { return {Fq::one(), Fq::zero()}; }
+    bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    bool operator==(const F2& o) const { return c0 == o.c0 && c1 == o.c1; }
+};
+F2 operator+(const F2& a, const F2& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+F2 operator-(const F2& a, const F2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
+F2 neg(const F2& a) { return {Fq::neg(a.c0), Fq::neg(a.c1)}; }
+F2 conj(const F2& a) { return {a.c0, Fq::neg(a.c1)}; }
+F2 operator*(const F2& a, const F2& b) {          // (a0 + a1 i)(b0 + b1 i), i^2 = -1 (Karatsuba)
+    Fq t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
+    return {t0 - t1, (a.c0 + a.c1) * (b.c0 + b.c1) - t0 - t1};
+}
+F2 sqr(const F2& a) { return {(a.c0 + a.c1) * (a.c0 - a.c1), Fq::dbl(a.c0 * a.c1)}; }
+F2 scale(const F2& a, const Fq& k) { return {a.c0 * k, a.c1 * k}; }
+F2 inv(const F2& a) {
+    Fq d = Fq::inv(Fq::sqr(a.c0) + Fq::sqr(a.c1));
+    return {a.c0 * d, Fq::neg(a.c1) * d};
+}
+F2 mul_xi(const F2& a) {                          // * (9 + i)
+    Fq n0 = Fq::dbl(Fq::dbl(Fq::dbl(a.c0))) + a.c0, n1 = Fq::dbl(Fq::dbl(Fq::dbl(a.c1))) + a.c1;
+    return {n0 - a.c1, n1 + a.c0};
+}
+
+// Fq12 = Fq2[w] / (w^6 - xi)
+struct F12 {
+    F2 c[6];
+    static F12 one() {
+        F12 r;
+        for (auto& x : r.c) x = F2::zero();
+        r.c[0] = F2::one();
+        return r;
+    }
+    bool is_one() const {
+        if (!(c[0] == F2::one())) return false;
+        for (int i = 1; i < 6; i++)
+            if (!c[i].is_zero()) return false;
+        return true;
+    }
+};
+F12 mul(const F12& a, const F12& b) {
+    F2 t[11];
+    for (auto& x : t) x = F2::zero();
+    for (int i = 0; i < 6; i++) {
+        if (a.c[i].is_zero()) continue;
+        for (int j = 0; j < 6; j++) {
+            if (b.c[j].is_zero()) continue;
+            t[i + j] = t[i + j] + a.c[i] * b.c[j];
+        }
+    }
+    F12 r;
+    for (int k = 0; k < 6; k++) r.c[k] = k < 5 ? t[k] + mul_xi(t[k + 6]) : t[k];
+    return r;
+}
+
+struct G2A {          // affine point on the twist y^2 = x^3 + 3/xi; inf = flag
+    F2 x, y;
+    bool inf = false;
+};
+
+struct PairingConsts {
+    F2 g12, g13, b2, g2x, g2y;
+    Fq g22, g23;
+    PairingConsts() {
+        g12 = {fq_from_words(PAIRING_G12[0]), fq_from_words(PAIRING_G12[1])};
+        g13 = {fq_from_words(PAIRING_G13[0]), fq_from_words(PAIRING_G13[1])};
+        b2 = {fq_from_words(PAIRING_B2[0]), fq_from_words(PAIRING_B2[1])};
+        g2x = {fq_from_words(PAIRING_G2X[0]), fq_from_words(PAIRING_G2X[1])};
+        g2y = {fq_from_words(PAIRING_G2Y[0]), fq_from_words(PAIRING_G2Y[1])};
+        g22 = fq_from_words(PAIRING_G22);
+        g23 = fq_from_words(PAIRING_G23);
+    }
+};
+const PairingConsts& PC_() {
+    static const PairingConsts c;
+    return c;
+}
+
+bool g2_on_curve(const G2A& q) {
+    if (q.inf) return true;
+    return sqr(q.y) == sqr(q.x) * q.x + PC_().b2;
+}
+
+G2A g2_add(const G2A& a, const G2A& b) {
+    if (a.inf) return b;
+    if (b.inf) return a;
+    F2 lam;
+    if (a.x == b.x) {
+        if ((a.y + b.y).is_zero()) { G2A r; r.inf = true; return r; }
+        F2 x2 = sqr(a.x);
+        lam = (x2 + x2 + x2) * inv(a.y + a.y);
+    } else {
+        lam = (b.y - a.y) * inv(b.x - a.x);
+    }
+    G2A r;
+    r.x = sqr(lam) - a.x - b.x;
+    r.y = lam * (a.x - r.x) - a.y;
+    return r;
+}
+
+G2A g2_mul(const G2A& q, const Fr& k_raw) {
+    G2A acc;
+    acc.inf = true;
+    for (int i = 253; i >= 0; i--) {
+        acc = g2_add(acc, acc);
+        if ((k_raw.l[i >> 5] >> (i & 31)) & 1) acc = g2_add(acc, q);
+    }
+    return acc;
+}
+
+// line through the untwisted t, q (tangent when equal) at P = (px, py); advances t <- t + q
+F12 line_and_add(G2A& t, const G2A& q, const Fq& px, const Fq& py) {
+    F2 lam;
+    if (t.x == q.x && t.y == q.y) {
+        F2 x2 = sqr(t.x);
+        lam = (x2 + x2 + x2) * inv(t.y + t.y);
+    } else {
+        lam = (q.y - t.y) * inv(q.x - t.x);
+    }
+    F12 l;
+    for (auto& x : l.c) x = F2::zero();
+    l.c[0] = {py, Fq::zero()};
+    l.c[1] = scale(neg(lam), px);
+    l.c[3] = lam * t.x - t.y;
+    G2A r;
+    r.x = sqr(lam) - t.x - q.x;
+    r.y = lam * (t.x - r.x) - t.y;
+    t = r;
+    return l;
+}
+
+F12 miller(const G1Affine& p, const G2A& q) {
+    if (p.is_inf() || q.inf) return F12::one();
+    F12 f = F12::one();
+    G2A t = q;
+    for (int i = (int)PAIRING_ATE_BITS - 2; i >= 0; i--) {
+        F12 l = line_and_add(t, t, p.x, p.y);
+        f = mul(mul(f, f), l);
+        if ((PAIRING_ATE[i >> 5] >> (i & 31)) & 1) {
+            l = line_and_add(t, q, p.x, p.y);
+            f = mul(f, l);
+        }
+    }
+    const PairingConsts& K = PC_();
+    G2A q1, q2n;
+    q1.x = conj(q.x) * K.g12;
+    q1.y = conj(q.y) * K.g13;
+    q2n.x = scale(q.x, K.g22);
+    q2n.y = neg(scale(q.y, K.g23));
+    F12 l = line_and_add(t, q1, p.x, p.y);
+    f = mul(f, l);
+    l = line_and_add(t, q2n, p.x, p.y);
+    return mul(f, l);
+}
+
+F12 final_exp(const F12& f) {
+    F12 r = F12::one();
+    for (int i = (int)PAIRING_FINAL_EXP_BITS - 1; i >= 0; i--) {
+        r = mul(r, r);
+        if ((PAIRING_FINAL_EXP[i >> 5] >> (i & 31)) & 1) r = mul(r, f);
+    }
+    return r;
+}
+
+G2A g2_from_bytes(const uint8_t b[128]) {
+    G2A q;
+    Fq v[4];
+    for (int c = 0; c < 4; c++) {
+        Fq raw;
+        memcpy(raw.l, b + 32 * c, 32);
+        SHP_REQUIRE(!raw.geq_p(), SHP_ERR_FORMAT, "verify: G2 coordinate not reduced");
+        v[c] = Fq::from_raw(raw);
+    }
+    q.x = {v[0], v[1]};
+    q.y = {v[2], v[3]};
+    SHP_REQUIRE(g2_on_curve(q), SHP_ERR_FORMAT, "verify: G2 point not on the twist");
+    return q;
+}
+
+void g2_to_bytes(const G2A& q, uint8_t out[128]) {
+    const Fq* v[4] = {&q.x.c0, &q.x.c1, &q.y.c0, &q.y.c1};
+    for (int c = 0; c < 4; c++) {
+        Fq raw = v[c]->to_raw();
+        memcpy(out + 32 * c, raw.l, 32);
+    }
+}
+
+// ------------------------------------------------------------------------------ G1 helpers (host)
+G1X g1_mul_fr(const G1X& p, const Fr& k_mont) {
+    const Fr k = k_mont.to_raw();
+    G1X acc = G1X::inf();
+    bool started = false;
+    for (int i = 253; i >= 0; i--) {
+        if (started) acc = g1_dbl(acc);
+        if ((k.l[i >> 5] >> (i & 31)) & 1) {
+            acc = started ? g1_add(acc, p) : p;
+            started = true;
+        }
+    }
+    return acc;
+}
+
+bool read_point(const uint8_t* b, G1Affine& out) {
+    Fq x, y;
+    for (int i = 0; i < 8; i++) {
+        x.l[i] = ((uint32_t)b[31 - 4 * i]) | ((uint32_t)b[30 - 4 * i] << 8) | ((uint32_t)b[29 - 4 * i] << 16) | ((uint32_t)b[28 - 4 * i] << 24);
+        y.l[i] = ((uint32_t)b[63 - 4 * i]) | ((uint32_t)b[62 - 4 * i] << 8) | ((uint32_t)b[61 - 4 * i] << 16) | ((uint32_t)b[60 - 4 * i] << 24);
+    }
+    if (x.geq_p() || y.geq_p()) return false;            // Halo2Verifier.sol:89-99: coordinates < q
+    out.x = Fq::from_raw(x);
+    out.y = Fq::from_raw(y);
+    return Fq::sqr(out.y) == Fq::sqr(out.x) * out.x + Fq::from_u64(3);
+}
+
+bool read_scalar(const uint8_t* b, Fr& out) {
+    Fr raw;
+    for (int i = 0; i < 8; i++)
+        raw.l[i] = ((uint32_t)b[31 - 4 * i]) | ((uint32_t)b[30 - 4 * i] << 8) | ((uint32_t)b[29 - 4 * i] << 16) | ((uint32_t)b[28 - 4 * i] << 24);
+    if (raw.geq_p()) return false;                        // Halo2Verifier.sol:291
+    out = Fr::from_raw(raw);
+    return true;
+}
+
+// the plan's expression programs over scalars (the verifier evaluates them at the claimed openings)
+template <class FA, class FF, class FI>
+std::vector<Fr> run_program_scalar(const std::vector<Instr>& prog, uint32_t nslots, const std::vector<Fr>& consts, FA adv, FF fix,
+                                   FI inst) {
+    std::vector<Fr> slots(nslots, Fr::zero()), outs;
+    for (const Instr& in : prog) {
+        switch (in.op) {
+            case OP_CONST: slots[in.dst] = consts[in.a]; break;
+            case OP_ADV: slots[in.dst] = adv(in.a); break;
+            case OP_FIX: slots[in.dst] = fix(in.a); break;
+            case OP_INST: slots[in.dst] = inst(in.a); break;
+            case OP_ADD: slots[in.dst] = slots[in.a] + slots[in.b]; break;
+            case OP_SUB: slots[in.dst] = slots[in.a] - slots[in.b]; break;
+            case OP_MUL: slots[in.dst] = slots[in.a] * slots[in.b]; break;
+            case OP_NEG: slots[in.dst] = Fr::neg(slots[in.a]); break;
+            case OP_OUT: outs.push_back(slots[in.a]); break;
+            default: break;
+        }
+    }
+    return outs;
+}
+
+}  // namespace
+
+static bool verify_impl(const VkView& vk, const uint8_t* proof, size_t proof_len, const uint8_t* inst_le32, size_t n_inst) {
+    const PlanData& P = *vk.plan;
+    const uint32_t n = P.n, L = (uint32_t)P.lookups.size(), S = P.num_sets, PC = (uint32_t)P.perm_cols.size();
+    const uint32_t A = P.num_advice;
+    const uint32_t n_points = A + 2 * L + S + L + 1 + (P.degree - 1);
+    const uint32_t n_evals = (uint32_t)(P.adv_q.size() + P.fix_q.size() + 1 + PC + (S ? 3 * S - 1 : 0) + 5 * L);
+    if (proof_len != (size_t)64 * n_points + 32 * n_evals + 128 || n_inst != P.num_instance) return false;
+    std::vector<Fr> instances(n_inst);
+    for (size_t i = 0; i < n_inst; i++) {
+        Fr raw;
+        memcpy(raw.l, inst_le32 + 32 * i, 32);
+        if (raw.geq_p()) return false;
+        instances[i] = Fr::from_raw(raw);
+    }
+    size_t pos = 0;
+    Transcript tr(vk.vk_digest);
+    for (auto& v : instances) tr.common_scalar(v);
+    bool ok = true;
+    auto rd_point = [&]() {
+        G1Affine p;
+        p.x = Fq::zero(); p.y = Fq::zero();
+        if (!read_point(proof + pos, p)) ok = false;
+        tr.buf.insert(tr.buf.end(), proof + pos, proof + pos + 64);
+        pos += 64;
+        return p;
+    };
+    std::vector<G1Affine> adv_c(A);
+    for (auto& p : adv_c) p = rd_point();
+    const Fr theta = tr.squeeze();
+    std::vector<G1Affine> lpi_c(L), lpt_c(L);
+    for (uint32_t l = 0; l < L; l++) { lpi_c[l] = rd_point(); lpt_c[l] = rd_point(); }
+    const Fr beta = tr.squeeze();
+    const Fr gamma = tr.squeeze();
+    std::vector<G1Affine> pz_c(S), lz_c(L);
+    for (auto& p : pz_c) p = rd_point();
+    for (auto& p : lz_c) p = rd_point();
+    const G1Affine rand_c = rd_point();
+    const Fr y = tr.squeeze();
+    std::vector<G1Affine> h_c(P.degree - 1);
+    for (auto& p : h_c) p = rd_point();
+    const Fr x = tr.squeeze();
+    std::vector<Fr> evs(n_evals);
+    for (auto& v : evs) {
+        if (!read_scalar(proof + pos, v)) return false;
+        tr.buf.insert(tr.buf.end(), proof + pos, proof + pos + 32);
+        pos += 32;
+    }
+    const Fr zeta_c = tr.squeeze();
+    const Fr nu = tr.squeeze();
+    const G1Affine Wc = rd_point();
+    const Fr mu = tr.squeeze();
+    const G1Affine Wp = rd_point();
+    if (!ok) return false;
+
+    // claimed evaluations by (kind, idx, rot)
+    std::map<std::tuple<int, uint32_t, int32_t>, Fr> ev;
+    size_t it = 0;
+    for (auto& q : P.adv_q) ev[{0, q.col, q.rot}] = evs[it++];
+    for (auto& q : P.fix_q) ev[{5, q.col, q.rot}] = evs[it++];
+    ev[{8, 0, 0}] = evs[it++];
+    for (uint32_t i = 0; i < PC; i++) ev[{6, i, 0}] = evs[it++];
+    for (uint32_t s = 0; s < S; s++) {
+        ev[{1, s, 0}] = evs[it++];
+        ev[{1, s, 1}] = evs[it++];
+        if (s + 1 != S) ev[{1, s, P.rot_last}] = evs[it++];
+    }
+    for (uint32_t l = 0; l < L; l++) {
+        ev[{2, l, 0}] = evs[it++]; ev[{2, l, 1}] = evs[it++]; ev[{3, l, 0}] = evs[it++]; ev[{3, l, -1}] = evs[it++];
+        ev[{4, l, 0}] = evs[it++];
+    }
+    // Lagrange data (Halo2Verifier.sol:392-470)
+    const Fr one = Fr::one();
+    const Fr xn = Fr::pow_u64(x, n);
+    const Fr n_inv = Fr::inv(Fr::from_u64(n));
+    const Fr omega_inv = Fr::inv(vk.omega);
+    auto lag = [&](int32_t i) {
+        Fr wi = i >= 0 ? Fr::pow_u64(vk.omega, (uint64_t)i) : Fr::pow_u64(omega_inv, (uint64_t)(-i));
+        return (xn - one) * n_inv * wi * Fr::inv(x - wi);
+    };
+    const int32_t lw = (int32_t)P.bf + 1;
+    const Fr l_last = lag(-lw);
+    Fr l_blind = Fr::zero();
+    for (int32_t i = -lw + 1; i < 0; i++) l_blind = l_blind + lag(i);
+    const Fr l_0 = lag(0);
+    Fr inst_eval = Fr::zero();
+    for (size_t i = 0; i < n_inst; i++) inst_eval = inst_eval + lag((int32_t)i) * instances[i];
+    const Fr l_act = one - l_last - l_blind;
+    auto advq = [&](uint32_t q) { return ev.at({0, P.adv_q[q].col, P.adv_q[q].rot}); };
+    auto fixq = [&](uint32_t q) { return ev.at({5, P.fix_q[q].col, P.fix_q[q].rot}); };
+    auto instq = [&](uint32_t) { return inst_eval; };
+    Fr numer = Fr::zero();
+    for (const Fr& e : run_program_scalar(P.gate_prog, P.gate_slots, P.consts, advq, fixq, instq)) numer = numer * y + e;
+    auto col_eval = [&](uint32_t t, uint32_t i) { return t == COL_ADVICE ? ev.at({0, i, 0}) : t == COL_FIXED ? ev.at({5, i, 0}) : inst_eval; };
+    if (S) {
+        const Fr z0 = ev.at({1, 0, 0});
+        numer = numer * y + l_0 * (one - z0);
+        const Fr zl = ev.at({1, S - 1, 0});
+        numer = numer * y + l_last * (Fr::sqr(zl) - zl);
+        for (uint32_t s = 1; s < S; s++) numer = numer * y + l_0 * (ev.at({1, s, 0}) - ev.at({1, s - 1, P.rot_last}));
+        Fr dpow = Fr::one();                          // delta^ci
+        for (uint32_t s = 0; s < S; s++) {
+            Fr lhs = ev.at({1, s, 1}), rhs = ev.at({1, s, 0});
+            for (uint32_t ci = s * P.chunk; ci < std::min<uint32_t>((s + 1) * P.chunk, PC); ci++) {
+                const Fr v = col_eval(P.perm_cols[ci].first, P.perm_cols[ci].second);
+                lhs = lhs * (v + beta * ev.at({6, ci, 0}) + gamma);
+                rhs = rhs * (v + beta * dpow * x + gamma);
+                dpow = dpow * vk.delta;
+            }
+            numer = numer * y + l_act * (lhs - rhs);
+        }
+    }
+    for (uint32_t l = 0; l < L; l++) {
+        const LookupPlan& lk = P.lookups[l];
+        auto comp = [&](const std::vector<Instr>& prog, uint32_t ns) {
+            Fr acc = Fr::zero();
+            bool first = true;
+            for (const Fr& e : run_program_scalar(prog, ns, P.consts, advq, fixq, instq)) {
+                acc = first ? e : acc * theta + e;
+                first = false;
+            }
+            return acc;
+        };
+        const Fr Ain = comp(lk.in_prog, lk.in_slots), Stab = comp(lk.tab_prog, lk.tab_slots);
+        const Fr z = ev.at({2, l, 0}), zn = ev.at({2, l, 1}), a_ = ev.at({3, l, 0}), ap = ev.at({3, l, -1}), s_ = ev.at({4, l, 0});
+        numer = numer * y + l_0 * (one - z);
+        numer = numer * y + l_last * (Fr::sqr(z) - z);
+        numer = numer * y + l_act * (zn * (a_ + beta) * (s_ + gamma) - z * (Ain + beta) * (Stab + gamma));
+        numer = numer * y + l_0 * (a_ - s_);
+        numer = numer * y + l_act * (a_ - s_) * (a_ - ap);
+    }
+    if ((xn - one).is_zero()) return false;
+    ev[{7, 0, 0}] = numer * Fr::inv(xn - one);        // h(x)
+    // commitment to h: sum_i x^(n i) H_i
+    G1X h_comm = G1X::inf();
+    for (size_t i = h_c.size(); i-- > 0;) h_comm = g1_add(g1_mul_fr(h_comm, xn), G1X::from_affine(h_c[i]));
+    auto comm = [&](int kind, uint32_t idx) -> G1X {
+        switch (kind) {
+            case 0: return G1X::from_affine(adv_c[idx]);
+            case 1: return G1X::from_affine(pz_c[idx]);
+            case 2: return G1X::from_affine(lz_c[idx]);
+            case 3: return G1X::from_affine(lpi_c[idx]);
+            case 4: return G1X::from_affine(lpt_c[idx]);
+            case 5: return G1X::from_affine((*vk.fixed_comm)[idx]);
+            case 6: return G1X::from_affine((*vk.sigma_comm)[idx]);
+            case 7: return h_comm;
+            default: return G1X::from_affine(rand_c);
+        }
+    };
+    // SHPLONK (bdfg21.rs)
+    const std::vector<int32_t>& superset = *vk.superset;
+    std::map<int32_t, Fr> point;
+    for (int32_t r : superset) point[r] = x * (r >= 0 ? Fr::pow_u64(vk.omega, (uint64_t)r) : Fr::pow_u64(omega_inv, (uint64_t)(-r)));
+    Fr z0v = Fr::one();
+    for (int32_t r : vk.sets[0].first) z0v = z0v * (mu - point[r]);
+    std::vector<Fr> diffs;
+    for (auto& st : vk.sets) {
+        Fr d = Fr::one();
+        for (int32_t r : superset)
+            if (std::find(st.first.begin(), st.first.end(), r) == st.first.end()) d = d * (mu - point[r]);
+        diffs.push_back(d);
+    }
+    if (diffs[0].is_zero()) return false;
+    const Fr d0inv = Fr::inv(diffs[0]);
+    G1X acc_pt = G1X::inf();
+    Fr r_total = Fr::zero(), nu_pow = Fr::one();
+    for (size_t si = 0; si < vk.sets.size(); si++) {
+        const auto& rots = vk.sets[si].first;
+        const auto& keys = vk.sets[si].second;
+        std::map<int32_t, Fr> co;
+        Fr csum = Fr::zero();
+        for (int32_t ri : rots) {
+            Fr c = mu - point[ri];
+            for (int32_t rj : rots)
+                if (rj != ri) c = c * (point[ri] - point[rj]);
+            if (c.is_zero()) return false;
+            co[ri] = Fr::inv(c);
+            csum = csum + co[ri];
+        }
+        if (csum.is_zero()) return false;
+        Fr r_eval = Fr::zero(), zp = Fr::one();
+        for (auto& key : keys) {
+            Fr inner = Fr::zero();
+            for (int32_t r : rots) inner = inner + co[r] * ev.at({key.first, key.second, r});
+            r_eval = r_eval + zp * inner;
+            zp = zp * zeta_c;
+        }
+        G1X F = G1X::inf();
+        for (size_t j = keys.size(); j-- > 0;) F = g1_add(g1_mul_fr(F, zeta_c), comm(keys[j].first, keys[j].second));
+        r_eval = r_eval * Fr::inv(csum);
+        const Fr coef = nu_pow * diffs[si] * d0inv;
+        r_total = r_total + coef * r_eval;
+        acc_pt = g1_add(acc_pt, g1_mul_fr(F, coef));
+        nu_pow = nu_pow * nu;
+    }
+    G1X G;
+    G.x = Fq::from_u64(1); G.y = Fq::from_u64(2); G.zz = Fq::one(); G.zzz = Fq::one();
+    G1X lhs = g1_add(acc_pt, g1_mul_fr(G, Fr::neg(r_total)));
+    lhs = g1_add(lhs, g1_mul_fr(G1X::from_affine(Wc), Fr::neg(z0v)));
+    lhs = g1_add(lhs, g1_mul_fr(G1X::from_affine(Wp), mu));
+    // e(lhs, g2) e(W', -s g2) = 1   (Halo2Verifier.sol:553-559)
+    SHP_REQUIRE(vk.has_g2, SHP_ERR_INVALID_ARG, "verify: the SRS of this key carries no G2 part");
+    const G2A g2 = g2_from_bytes(vk.g2);
+    G2A ns = g2_from_bytes(vk.s_g2);
+    ns.y = neg(ns.y);
+    const F12 f = mul(miller(g1_to_affine(lhs), g2), miller(Wp, ns));
+    return final_exp(f).is_one();
+}
+
+// s_g2 = tau * G2 for a synthetic SRS (capi.hip: shp_srs_synthetic); g2 = the standard generator
+void shp_synthetic_g2(const Fr& tau_mont, uint8_t g2_out[128], uint8_t s_g2_out[128]) {
+    G2A g;
+    g.x = PC_().g2x;
+    g.y = PC_().g2y;
+    g2_to_bytes(g, g2_out);
+    g2_to_bytes(g2_mul(g, tau_mont.to_raw()), s_g2_out);
+}
+
+extern "C" int32_t shp_verify(const shp_pk* pk, const uint8_t* proof, size_t proof_len, const uint8_t* instances_le32,
+                              size_t n_instances, int32_t* accepted) {
+    return guarded([&] {
+        SHP_REQUIRE(pk && proof && accepted && (instances_le32 || n_instances == 0), SHP_ERR_INVALID_ARG, "verify: null argument");
+        VkView vk;
+        shp_pk_vk_view(pk, vk);
+        *accepted = verify_impl(vk, proof, proof_len, instances_le32, n_instances) ? 1 : 0;
+    });
+}
