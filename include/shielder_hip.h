@@ -80,6 +80,12 @@ int32_t shp_download(shp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
 int32_t shp_fr_from_le32(const uint8_t in[32], uint64_t out[4]);
 int32_t shp_fr_to_le32(const uint64_t in[4], uint8_t out[32]);
 
+/* Witness-side secret derivation (/root/reference/crates/shielder-account/src/secrets.rs:27-56, KATs :75-106):
+ * Keccak-256(value as 32 big-endian bytes | label | big-endian counters) reduced mod r.  Values cross as
+ * canonical 32-byte little-endian integers (id and private_key are arbitrary 256-bit values).  Host only. */
+int32_t shp_derive_nullifier(const uint8_t id_le32[32], uint32_t nonce, uint8_t out_le32[32]);
+int32_t shp_derive_id(const uint8_t private_key_le32[32], uint64_t chain_id, uint32_t account_nonce, uint8_t out_le32[32]);
+
 /* halo2_verifier::encode_calldata(proof, instances)
  * (/root/reference/crates/halo2-verifier/src/lib/verifier_contract.rs:6-20): ABI encoding of
  * Halo2Verifier.verifyProof(bytes proof, uint256[] instances), selector 0x1e8e1e13 -- the bytes the
@@ -195,6 +201,12 @@ int32_t shp_prove(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, c
  * permutations of the Merkle levels run side by side).  Default 4 (env SHP_WITNESS_THREADS); a
  * proving pool with more than 4 lanes sets 1 -- throughput does not need it, latency does. */
 int32_t shp_prover_witness_threads(shp_prover* p, uint32_t threads);
+/* ProverKnowledge::serialize_public_input without proving -- the `*_pub_inputs` entry points of the bindings
+ * (/root/reference/crates/shielder_bindings/src/circuits/withdraw.rs:150-174; the TEE answers every request with
+ * them, tee/.../server.rs:186-193): runs the plan's witness program on the host and returns the public inputs
+ * (32-byte LE canonical, instance order).  No GPU work. */
+int32_t shp_public_inputs(const shp_pk* pk, const uint8_t* witness_le32, size_t n_inputs, uint8_t* instances_le32,
+                          size_t instances_cap);
 /* shielder_circuits::verify(&params, &vk, &proof, &pub_input)
  * (/root/reference/crates/shielder_bindings/src/circuits/mod.rs:113-124): the verifier the reference's
  * generator emits as Solidity (crates/halo2-verifier/templates/Halo2Verifier.sol, pcs/bdfg21.rs), on

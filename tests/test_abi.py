@@ -77,3 +77,14 @@ def test_encode_calldata_matches_abi_encoding(shp, oracle):
     with pytest.raises(shp.ShpError) as e:
         shp.encode_calldata(b"\x01", [R])
     assert e.value.code == 4
+
+
+def test_secret_derivation_reference_kats(shp):
+    """crates/shielder-account/src/secrets.rs:75-106: the reference's two known-answer tests, through the library"""
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    before = 0x375a07a9503d15a291307e33ad0c297c9768fea4712947172ad09f2df34d8015
+    assert shp.derive_nullifier(15, 0xFF) == before % R != before
+    before = 0xf4b3b097dfb3da737872bdf8b59a3b3723345dc147a0b8229608db69cfef6499
+    assert shp.derive_id(16, 26, 45) == before % R != before
+    # arbitrary 256-bit inputs are accepted (U256, not a field element)
+    assert 0 <= shp.derive_id(2**256 - 1, 2**64 - 1, 2**32 - 1) < R

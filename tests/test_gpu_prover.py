@@ -321,6 +321,7 @@ def test_native_verifier_matches_oracle(shp, oracle, gpu_ctx):
     pr = shp.Prover(pk)
     proof, inst = pr.prove(wit, bytes([7]) * 32)
     assert pk.verify(proof, inst) and PL.verify(opk, proof, inst, tau=TAU) and PL.verify(opk, proof, inst, g2=g2, s_g2=s_g2)
+    assert pk.public_inputs(wit) == inst                     # *_pub_inputs without proving
     rnd = random.Random(1)
     positions = [0, 63, 64 * 10 + 5, 64 * 15, len(proof) - 129, len(proof) - 128, len(proof) - 1] + [rnd.randrange(len(proof)) for _ in range(8)]
     for pos in positions:

@@ -296,6 +296,13 @@ class ProvingKey:
         _check(lib().shp_pk_save(self.h, out, C.c_size_t(n.value), C.byref(n)))
         return out.raw[:n.value]
 
+    def public_inputs(self, witness_ints):
+        """*_pub_inputs of the bindings: the circuit's public inputs for a witness, without proving"""
+        wit = b"".join(int(x).to_bytes(32, "little") for x in witness_ints)
+        out = C.create_string_buffer(max(1, 32 * self.n_instances))
+        _check(lib().shp_public_inputs(self.h, C.c_char_p(wit), C.c_size_t(len(witness_ints)), out, C.c_size_t(len(out.raw))))
+        return [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(self.n_instances)]
+
     def verify(self, proof: bytes, instances) -> bool:
         """Circuit::verify (crates/shielder_bindings/src/circuits/mod.rs:113-124): native verifier incl. pairing"""
         ins = b"".join(int(x).to_bytes(32, "little") for x in instances)
@@ -397,6 +404,20 @@ class MerkleTree:
         if self.h:
             lib().shp_merkle_destroy(self.h)
             self.h = C.c_void_p()
+
+
+def derive_nullifier(ident: int, nonce: int) -> int:
+    """shielder_account::secrets::nonced::derive_nullifier (secrets.rs:37-44)"""
+    out = C.create_string_buffer(32)
+    _check(lib().shp_derive_nullifier(C.c_char_p(int(ident).to_bytes(32, "little")), C.c_uint32(nonce), out))
+    return int.from_bytes(out.raw, "little")
+
+
+def derive_id(private_key: int, chain_id: int, account_nonce: int) -> int:
+    """shielder_account::secrets::derive_id (secrets.rs:48-55)"""
+    out = C.create_string_buffer(32)
+    _check(lib().shp_derive_id(C.c_char_p(int(private_key).to_bytes(32, "little")), C.c_uint64(chain_id), C.c_uint32(account_nonce), out))
+    return int.from_bytes(out.raw, "little")
 
 
 def encode_calldata(proof: bytes, instances) -> bytes:

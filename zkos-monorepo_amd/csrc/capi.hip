@@ -262,6 +262,39 @@ int32_t shp_fr_to_le32(const uint64_t in[4], uint8_t out[32]) {
     });
 }
 
+// Keccak(label-separated big-endian fields) mod r  (shielder-account/src/secrets.rs:27-56)
+static void derive_secret(const uint8_t first_le32[32], const char* label, const uint8_t* tail, size_t tail_len, uint8_t out_le32[32]) {
+    std::vector<uint8_t> msg;
+    for (int i = 31; i >= 0; i--) msg.push_back(first_le32[i]);            // U256::to_be_bytes
+    msg.insert(msg.end(), label, label + strlen(label));
+    msg.insert(msg.end(), tail, tail + tail_len);
+    uint8_t h[32];
+    keccak256(msg.data(), msg.size(), h);
+    Fr raw;                                                                // U256::from_be_slice(hash)
+    for (int i = 0; i < 8; i++)
+        raw.l[i] = ((uint32_t)h[31 - 4 * i]) | ((uint32_t)h[30 - 4 * i] << 8) | ((uint32_t)h[29 - 4 * i] << 16) | ((uint32_t)h[28 - 4 * i] << 24);
+    Fr red = Fr::from_raw(raw).to_raw();                                   // reduce_mod(FIELD_MODULUS)
+    memcpy(out_le32, red.l, 32);
+}
+
+int32_t shp_derive_nullifier(const uint8_t id_le32[32], uint32_t nonce, uint8_t out_le32[32]) {
+    return guarded([&] {
+        SHP_REQUIRE(id_le32 && out_le32, SHP_ERR_INVALID_ARG, "derive_nullifier: null argument");
+        const uint8_t tail[4] = {(uint8_t)(nonce >> 24), (uint8_t)(nonce >> 16), (uint8_t)(nonce >> 8), (uint8_t)nonce};
+        derive_secret(id_le32, "nullifier", tail, 4, out_le32);
+    });
+}
+
+int32_t shp_derive_id(const uint8_t private_key_le32[32], uint64_t chain_id, uint32_t account_nonce, uint8_t out_le32[32]) {
+    return guarded([&] {
+        SHP_REQUIRE(private_key_le32 && out_le32, SHP_ERR_INVALID_ARG, "derive_id: null argument");
+        uint8_t tail[12];
+        for (int i = 0; i < 8; i++) tail[i] = (uint8_t)(chain_id >> (8 * (7 - i)));
+        for (int i = 0; i < 4; i++) tail[8 + i] = (uint8_t)(account_nonce >> (8 * (3 - i)));
+        derive_secret(private_key_le32, "id", tail, 12, out_le32);
+    });
+}
+
 int32_t shp_encode_calldata(const uint8_t* proof, size_t proof_len, const uint8_t* instances_le32, size_t n_instances,
                             uint8_t* out, size_t out_cap, size_t* out_len) {
     return guarded([&] {

@@ -1189,6 +1189,30 @@ int32_t shp_prover_create(shp_pk* pk, shp_prover** out) {
     return guarded([&] { prover_create_impl(pk, out); });
 }
 
+int32_t shp_public_inputs(const shp_pk* pk, const uint8_t* witness_le32, size_t n_inputs, uint8_t* instances_le32,
+                          size_t instances_cap) {
+    return guarded([&] {
+        SHP_REQUIRE(pk && witness_le32 && instances_le32, SHP_ERR_INVALID_ARG, "public_inputs: null argument");
+        const PlanData& P = pk->plan;
+        SHP_REQUIRE(n_inputs == P.n_winputs, SHP_ERR_INVALID_ARG, "public_inputs: wrong number of witness inputs");
+        SHP_REQUIRE(instances_cap >= (size_t)P.num_instance * 32, SHP_ERR_INVALID_ARG, "public_inputs: instance buffer too small");
+        std::vector<Fr> inputs(n_inputs);
+        for (size_t i = 0; i < n_inputs; i++) {
+            Fr raw;
+            memcpy(raw.l, witness_le32 + 32 * i, 32);
+            SHP_REQUIRE(!raw.geq_p(), SHP_ERR_FORMAT, "public_inputs: witness input is not a canonical field element");
+            inputs[i] = Fr::from_raw(raw);
+        }
+        // the witness program on the host, no GPU work: only the cells the public inputs are read from matter
+        std::vector<Fr> grid((size_t)P.num_advice * P.n, Fr::zero()), scratch(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
+        run_witness_range(P, inputs, grid.data(), scratch.data(), 0, (uint32_t)P.wops.size());
+        for (size_t i = 0; i < P.instance_map.size(); i++) {
+            Fr raw = grid[(size_t)P.instance_map[i].first * P.n + P.instance_map[i].second].to_raw();
+            memcpy(instances_le32 + 32 * i, raw.l, 32);
+        }
+    });
+}
+
 int32_t shp_prover_witness_threads(shp_prover* p, uint32_t threads) {
     return guarded([&] {
         SHP_REQUIRE(p, SHP_ERR_INVALID_ARG, "prover_witness_threads: null prover");
