@@ -4,6 +4,8 @@ import sys
 
 import pytest
 
+# the OpenMP oracle is fastest near 16 threads; a 256-thread default (GPU box) makes its small vectors crawl
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 8)))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
