@@ -56,6 +56,9 @@ struct KernelTimers {
     }
 };
 
+// rows of a scalar column that can be non-zero: [0, prefix) and [tail_start, tail_start + tail_count)
+struct MsmRows { uint32_t prefix, tail_start, tail_count; };
+
 // per-caller scratch of one MSM pipeline (a prover instance owns one per stream)
 struct MsmWorkspace {
     KernelTimers* timers = nullptr;
@@ -103,7 +106,10 @@ struct shp_srs {
 // `batch` MSMs over the plan's bases; synchronises `st` and normalises on the host
 void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const shp::Fr* d_scalars, size_t n_scalars, size_t stride,
                 uint32_t batch, shp::G1Affine* h_out, hipStream_t st);
+// `rows` (optional): the only rows of m's scalar columns that can be non-zero, [0, prefix) and
+// [tail_start, tail_start + tail_count); the direct-table path skips the rest without reading them
 void msm_run_ws2(shp_msm* m, const shp::Fr* d_scalars, size_t stride, uint32_t batch, shp_msm* m2, const shp::Fr* d_scalars2,
-                 size_t stride2, uint32_t batch2, size_t n_scalars, shp::MsmWorkspace& ws, shp::G1Affine* h_out, hipStream_t st);
+                 size_t stride2, uint32_t batch2, size_t n_scalars, shp::MsmWorkspace& ws, shp::G1Affine* h_out, hipStream_t st,
+                 const shp::MsmRows* rows = nullptr);
 void msm_run(shp_msm* m, const shp::Fr* d_scalars, size_t n_scalars, size_t stride, uint32_t batch,
              shp::G1Affine* h_out, hipStream_t st);

@@ -436,7 +436,11 @@ struct DirectArgs {
     const Fr* scalars[2];
     size_t stride[2];
     uint32_t split;
-    size_t n_scalars, n_table;
+    // scalars a segment actually visits: rows [0, prefix) and [tail_start, tail_start + tail_count)
+    // (a witness column is zero between its assigned rows and its blinding rows)
+    uint32_t prefix[2], tail_start[2], tail_count[2];
+    uint32_t gx[2];     // 256-row blocks per MSM of each segment
+    size_t n_table;
     uint32_t c, W, NB, T;
     Fr bias;
     G1X* partials;      // [batch][gridDim.y * gridDim.x]
@@ -603,17 +607,23 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
     return r;
 }
 
-// lane <-> scalar i, blockIdx.y <-> group of T windows, blockIdx.z <-> MSM of the batch
+// lane <-> scalar i, blockIdx.y <-> group of T windows, blockIdx.x <-> (MSM of the batch, 256-row block):
+// only row blocks a segment visits are launched (an empty workgroup still costs ~0.1 us of dispatch)
 __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a) {
     __shared__ uint32_t sh[COOP_LDS_WORDS];
-    const size_t i = (size_t)blockIdx.x * MSM_THREADS + threadIdx.x;
-    const uint32_t seg = blockIdx.z >= a.split ? 1u : 0u;
-    const uint32_t m = blockIdx.z - (seg ? a.split : 0u);
+    const uint32_t seg = blockIdx.x >= a.split * a.gx[0] ? 1u : 0u;
+    const uint32_t bx = blockIdx.x - (seg ? a.split * a.gx[0] : 0u);
+    const uint32_t m = bx / a.gx[seg], blk = bx % a.gx[seg];
+    const uint32_t lane = blk * MSM_THREADS + threadIdx.x;
+    const uint32_t visited = a.prefix[seg] + a.tail_count[seg];
+    // partials of MSM z: [gy][gx[seg]] at the segment's base
+    const size_t part = (seg ? (size_t)a.split * a.gx[0] * gridDim.y : 0) + ((size_t)m * gridDim.y + blockIdx.y) * a.gx[seg] + blk;
+    const size_t i = lane < a.prefix[seg] ? lane : (size_t)a.tail_start[seg] + (lane - a.prefix[seg]);
     const G1Affine* __restrict__ mult = a.mult[seg];
     const uint32_t w0 = blockIdx.y * a.T;
     const uint32_t w1 = w0 + a.T < a.W ? w0 + a.T : a.W;
     G1X acc = G1X::inf();
-    if (i < a.n_scalars) {
+    if (lane < visited) {
         Fr raw = load_fr(a.scalars[seg] + (size_t)m * a.stride[seg] + i).to_raw();
         if (!raw.is_zero()) {
             uint64_t cy = 0;
@@ -656,14 +666,16 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
         }
     }
     acc = block_sum_256(acc, sh);
-    if (threadIdx.x == 0) a.partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = acc;
+    if (threadIdx.x == 0) a.partials[part] = acc;
 }
 
-// one workgroup per MSM: sum of its P partials
-__global__ __launch_bounds__(MSM_THREADS) void msm_direct_final_kernel(const G1X* partials, uint32_t P, G1X* out) {
+// one workgroup per MSM: sum of its partials (P0 each for the first `split` MSMs, P1 for the rest)
+__global__ __launch_bounds__(MSM_THREADS) void msm_direct_final_kernel(const G1X* partials, uint32_t split, uint32_t P0,
+                                                                       uint32_t P1, G1X* out) {
     __shared__ uint32_t sh[COOP_LDS_WORDS];
     const uint32_t m = blockIdx.x;
-    const G1X* p = partials + (size_t)m * P;
+    const uint32_t P = m < split ? P0 : P1;
+    const G1X* p = partials + (m < split ? (size_t)m * P0 : (size_t)split * P0 + (size_t)(m - split) * P1);
     G1X acc = G1X::inf();
     for (uint32_t j = threadIdx.x; j < P; j += MSM_THREADS) acc = g1_add(acc, p[j]);
     acc = block_sum_256(acc, sh, P < MSM_THREADS ? P : MSM_THREADS);
@@ -791,11 +803,21 @@ static void normalise_batch(const std::vector<G1X>& in, uint32_t batch, G1Affine
 
 static void msm_run_direct(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n_scalars, size_t stride,
                            uint32_t batch, G1Affine* h_out, hipStream_t st, shp_msm* m2 = nullptr,
-                           const Fr* d_scalars2 = nullptr, size_t stride2 = 0, uint32_t batch2 = 0) {
+                           const Fr* d_scalars2 = nullptr, size_t stride2 = 0, uint32_t batch2 = 0,
+                           const shp::MsmRows* rows = nullptr) {
     const uint32_t W = m->W, total = batch + batch2;
+    // segment 0 may visit only its assigned rows; segment 1 is always dense
+    shp::MsmRows r0{(uint32_t)n_scalars, 0, 0};
+    if (rows) {
+        SHP_REQUIRE((size_t)rows->prefix <= rows->tail_start && (size_t)rows->tail_start + rows->tail_count <= n_scalars,
+                    SHP_ERR_INVALID_ARG, "msm: bad row ranges");
+        r0 = *rows;
+    }
+    const uint32_t visited0 = r0.prefix + r0.tail_count;
     if (batch2) SHP_REQUIRE(m2 && m2->direct && m2->n == m->n && m2->c == m->c && m2->W == W, SHP_ERR_INVALID_ARG,
                             "msm: the two segments need plans of the same shape");
-    const uint32_t gx = ceil_div(n_scalars, MSM_THREADS);
+    const uint32_t gx0 = ceil_div(std::max<uint32_t>(visited0, 1), MSM_THREADS), gx1 = ceil_div(n_scalars, MSM_THREADS);
+    const uint64_t busy_wgs = (uint64_t)gx0 * batch + (uint64_t)gx1 * batch2;
     // T windows per lane: all of them when the launch fills the chip anyway (least tree overhead),
     // shorter chains for small launches (latency)
     static const uint64_t base_waves = getenv("SHP_MSM_MIN_WAVES") ? (uint64_t)atol(getenv("SHP_MSM_MIN_WAVES")) : 1024;
@@ -804,23 +826,27 @@ static void msm_run_direct(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalar
     const uint32_t cand[6] = {W, (W + 1) / 2, 8, 4, 2, 1};
     uint32_t T = 1;
     for (uint32_t t : cand)
-        if (t <= W && (uint64_t)gx * (MSM_THREADS / 64) * ceil_div(W, t) * total >= min_waves) { T = t; break; }
+        if (t <= W && busy_wgs * (MSM_THREADS / 64) * ceil_div(W, t) >= min_waves) { T = t; break; }
     const uint32_t gy = ceil_div(W, T);
-    const uint32_t P = gx * gy;
-    ws.pf.reserve((size_t)total * P * sizeof(G1X));
+    const uint32_t P0 = gx0 * gy, P1 = gx1 * gy;
+    ws.pf.reserve(((size_t)batch * P0 + (size_t)batch2 * P1) * sizeof(G1X));
     ws.out.reserve((size_t)total * sizeof(G1X));
     DirectArgs a;
     a.mult[0] = m->d_mult; a.scalars[0] = d_scalars; a.stride[0] = stride;
     a.mult[1] = m2 ? m2->d_mult : m->d_mult; a.scalars[1] = d_scalars2; a.stride[1] = stride2;
     a.split = batch;
-    a.n_scalars = n_scalars; a.n_table = m->n;
+    a.prefix[0] = r0.prefix; a.tail_start[0] = r0.tail_start; a.tail_count[0] = r0.tail_count;
+    a.prefix[1] = (uint32_t)n_scalars; a.tail_start[1] = 0; a.tail_count[1] = 0;
+    a.gx[0] = gx0; a.gx[1] = gx1;
+    a.n_table = m->n;
     a.c = m->c; a.W = W; a.NB = m->NB; a.T = T; a.bias = m->bias; a.partials = ws.pf.as<G1X>();
     KernelTimers none, *tm = ws.timers ? ws.timers : &none;
     tm->begin(KID_MSM_DIRECT, st);
-    hipLaunchKernelGGL(msm_direct_kernel, dim3(gx, gy, total), dim3(MSM_THREADS), 0, st, a);
+    hipLaunchKernelGGL(msm_direct_kernel, dim3((uint32_t)busy_wgs, gy), dim3(MSM_THREADS), 0, st, a);
     tm->end(st);
     tm->begin(KID_MSM_DIRECT_FINAL, st);
-    hipLaunchKernelGGL(msm_direct_final_kernel, dim3(total), dim3(MSM_THREADS), 0, st, ws.pf.as<G1X>(), P, ws.out.as<G1X>());
+    hipLaunchKernelGGL(msm_direct_final_kernel, dim3(total), dim3(MSM_THREADS), 0, st, ws.pf.as<G1X>(), batch, P0, P1,
+                       ws.out.as<G1X>());
     tm->end(st);
     SHP_HIP(hipGetLastError());
     ws.h_out.resize(total);
@@ -828,18 +854,20 @@ static void msm_run_direct(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalar
     SHP_HIP(hipStreamSynchronize(st));
     tm->collect();
     normalise_batch(ws.h_out, total, h_out);
-    ws.last_adds = (uint64_t)total * n_scalars * W;           // upper bound: one mixed add per non-zero digit
-    ws.last_bytes = (uint64_t)total * n_scalars * 32 + (uint64_t)n_scalars * 64;
+    const uint64_t visited = (uint64_t)batch * visited0 + (uint64_t)batch2 * n_scalars;
+    ws.last_adds = visited * W;                               // upper bound: one mixed add per non-zero digit
+    ws.last_bytes = visited * 32 + (uint64_t)n_scalars * 64;
 }
 
 // `batch` MSMs over m and `batch2` over m2 (both direct-table plans of one shape) in ONE launch;
 // h_out receives batch + batch2 points
 void msm_run_ws2(shp_msm* m, const Fr* d_scalars, size_t stride, uint32_t batch, shp_msm* m2, const Fr* d_scalars2,
-                 size_t stride2, uint32_t batch2, size_t n_scalars, shp::MsmWorkspace& ws, G1Affine* h_out, hipStream_t st) {
+                 size_t stride2, uint32_t batch2, size_t n_scalars, shp::MsmWorkspace& ws, G1Affine* h_out, hipStream_t st,
+                 const shp::MsmRows* rows) {
     SHP_REQUIRE(m && m2 && d_scalars && d_scalars2 && h_out && batch && batch2, SHP_ERR_INVALID_ARG, "msm2: bad argument");
     SHP_REQUIRE(n_scalars <= m->n, SHP_ERR_INVALID_ARG, "msm: more scalars than bases");
     if (m->direct && m2->direct) {
-        msm_run_direct(m, ws, d_scalars, n_scalars, stride, batch, h_out, st, m2, d_scalars2, stride2, batch2);
+        msm_run_direct(m, ws, d_scalars, n_scalars, stride, batch, h_out, st, m2, d_scalars2, stride2, batch2, rows);
         return;
     }
     msm_run_ws(m, ws, d_scalars, n_scalars, stride, batch, h_out, st);

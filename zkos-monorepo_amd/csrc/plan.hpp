@@ -40,6 +40,7 @@ struct PlanData {
     uint8_t plan_hash[32];
     // derived
     uint32_t n = 0, usable = 0, ext_k = 0, chunk = 0, num_sets = 0;
+    uint32_t adv_rows = 0;       // rows [adv_rows, usable) of every advice column are never assigned (stay zero)
     int32_t rot_last = 0;
 
     static Fr read_fr(const uint8_t* p) {
@@ -182,6 +183,9 @@ inline void PlanData::parse(const uint8_t* d, size_t len) {
     }
     SHP_REQUIRE(off == len && nim == num_instance, SHP_ERR_FORMAT, "plan: trailing bytes or instance count mismatch");
     usable = n - (bf + 1);
+    for (auto& w : wops)
+        if (w.dc < num_advice) adv_rows = std::max(adv_rows, w.dr + 1);
+    adv_rows = std::min(adv_rows, usable);
     ext_k = k;
     while ((1ull << ext_k) < (uint64_t)n * (degree - 1)) ext_k++;
     chunk = degree - 2;

@@ -560,6 +560,9 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     const PlanData& P = pk->plan;
     const uint32_t n = pk->n, ne = pk->ne, NV = pk->NV, L = (uint32_t)P.lookups.size(), S = P.num_sets;
     pr->vals = pr->dalloc<Fr>((size_t)(NV + 1) * n);
+    // unassigned witness rows are never uploaded; on the prover's own stream (non-blocking: the null stream's
+    // memset would not be ordered before the first proof's uploads)
+    SHP_HIP(hipMemsetAsync(pr->vals, 0, (size_t)(NV + 1) * n * sizeof(Fr), pr->st));
     pr->polys = pr->dalloc<Fr>((size_t)(NV + 1) * n);
     pr->cos = pr->dalloc<Fr>((size_t)(NV + 1) * ne);
     pr->cin = pr->dalloc<Fr>((size_t)L * n);
@@ -730,8 +733,13 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     ctr += A;                                           // one (unused) commitment blind per advice column
     Fr* const instcol = grid + (size_t)A * n;           // rows past the instances stay zero (cleared at creation)
     for (size_t i = 0; i < instances.size(); i++) instcol[i] = instances[i];
-    SHP_HIP(hipMemcpyAsync(V(0), grid, (size_t)A * n * sizeof(Fr), hipMemcpyHostToDevice, st));
-    SHP_HIP(hipMemcpyAsync(V(I_INST), instcol, (size_t)n * sizeof(Fr), hipMemcpyHostToDevice, st));
+    // only the rows the witness program assigns and the blinding rows travel; the rest is zero on both sides
+    const size_t pitch = (size_t)n * sizeof(Fr);
+    if (A && P.adv_rows)
+        SHP_HIP(hipMemcpy2DAsync(V(0), pitch, grid, pitch, (size_t)P.adv_rows * sizeof(Fr), A, hipMemcpyHostToDevice, st));
+    if (A) SHP_HIP(hipMemcpy2DAsync(V(0) + u, pitch, grid + u, pitch, (size_t)(n - u) * sizeof(Fr), A, hipMemcpyHostToDevice, st));
+    if (!instances.empty())
+        SHP_HIP(hipMemcpyAsync(V(I_INST), instcol, instances.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
     SHP_HIP(hipMemcpyAsync(pr->key, key, 32, hipMemcpyHostToDevice, st));
     Transcript tr(pk->vk_digest);
     for (auto& v : instances) tr.common_scalar(v);
@@ -741,7 +749,8 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     const uint64_t ctr_rand = (uint64_t)A * nb + A + (uint64_t)L * (2 * nb + 2) + (uint64_t)(S + L) * (bf + 1);
     hipLaunchKernelGGL(chacha_fr_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->key, ctr_rand, n, pr->rand_poly);
     std::vector<G1Affine> pts(std::max<uint32_t>({A + 1, 2 * L, S + L + 1, P.degree}));
-    msm_run_ws2(srs->msm_gl, V(0), n, A, srs->msm_g, pr->rand_poly, n, 1, n, pr->msm_ws, pts.data(), st);
+    const MsmRows adv_rows{P.adv_rows, u, n - u};     // assigned rows + blinding rows; the rest is zero
+    msm_run_ws2(srs->msm_gl, V(0), n, A, srs->msm_g, pr->rand_poly, n, 1, n, pr->msm_ws, pts.data(), st, &adv_rows);
     const G1Affine rand_comm = pts[A];
     for (uint32_t c = 0; c < A; c++) tr.write_point(pts[c].x, pts[c].y);
     const Fr theta = tr.squeeze();
