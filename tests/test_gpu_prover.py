@@ -266,6 +266,9 @@ def test_witness_schedule_threads_give_identical_proofs(shp, oracle, gpu_ctx, sm
         pr.witness_threads(threads)
         for _ in range(3):
             assert pr.prove(wit, bytes([5]) * 32) == want, f"{threads} witness threads"
+    for throughput in (True, False):                     # shp_prover_mode: scheduling only, same bytes
+        pr.mode(throughput)
+        assert pr.prove(wit, bytes([5]) * 32) == want, f"mode throughput={throughput}"
     pr.close(); pk.close(); params.close()
 
 

@@ -351,6 +351,10 @@ class Prover:
         ins = [int.from_bytes(inst.raw[32 * i:32 * i + 32], "little") for i in range(self.pk.n_instances)]
         return proof.raw[:plen.value], ins
 
+    def mode(self, throughput: bool):
+        """shp_prover_mode: latency (default) or throughput scheduling of this lane"""
+        _check(lib().shp_prover_mode(self.h, C.c_uint32(1 if throughput else 0)))
+
     def witness_threads(self, n: int):
         """host threads for the witness program of this lane (default 4; 1 = sequential)"""
         _check(lib().shp_prover_witness_threads(self.h, C.c_uint32(n)))

@@ -66,6 +66,7 @@ struct MsmWorkspace {
     std::vector<G1X> h_out;
     std::vector<uint32_t> h_totals;
     uint64_t last_adds = 0, last_bytes = 0;
+    uint64_t min_waves = 0;     // direct mode: waves a launch should have before chains get longer (0 = default)
     void release() {
         cnt.release(); start.release(); entries.release(); pf.release(); pl.release(); buckets.release(); out.release();
         wg_hist.release();

@@ -822,7 +822,7 @@ static void msm_run_direct(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalar
     // shorter chains for small launches (latency)
     static const uint64_t base_waves = getenv("SHP_MSM_MIN_WAVES") ? (uint64_t)atol(getenv("SHP_MSM_MIN_WAVES")) : 1024;
     static const uint64_t big_waves = getenv("SHP_MSM_BIG_WAVES") ? (uint64_t)atol(getenv("SHP_MSM_BIG_WAVES")) : 1024;
-    const uint64_t min_waves = total >= 8 ? big_waves : base_waves;
+    const uint64_t min_waves = ws.min_waves ? ws.min_waves : total >= 8 ? big_waves : base_waves;
     const uint32_t cand[6] = {W, (W + 1) / 2, 8, 4, 2, 1};
     uint32_t T = 1;
     for (uint32_t t : cand)

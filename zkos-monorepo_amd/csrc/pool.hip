@@ -97,7 +97,7 @@ int32_t shp_pool_create(shp_pk* pk, uint32_t lanes, uint32_t queue_cap, shp_pool
                 for (auto* q : p->lanes) shp_prover_destroy(q);
                 throw shp::Error(rc, std::string("pool_create: ") + shp_last_error());
             }
-            if (lanes > 4) (void)shp_prover_witness_threads(pr, 1);   // many lanes: one host thread each is enough
+            if (lanes > 4) (void)shp_prover_mode(pr, 1);   // many lanes: one host thread each, long MSM chains
             p->lanes.push_back(pr);
         }
         shp_pool* raw = p.get();

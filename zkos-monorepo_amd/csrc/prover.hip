@@ -1229,6 +1229,14 @@ int32_t shp_prover_witness_threads(shp_prover* p, uint32_t threads) {
     });
 }
 
+int32_t shp_prover_mode(shp_prover* p, uint32_t mode) {
+    return guarded([&] {
+        SHP_REQUIRE(p && mode <= 1, SHP_ERR_INVALID_ARG, "prover_mode: null prover or unknown mode");
+        p->msm_ws.min_waves = mode ? 256 : 0;
+        if (mode) set_witness_threads(p, 1);
+    });
+}
+
 int32_t shp_prover_profile(shp_prover* p, int32_t enable) {
     return guarded([&] {
         SHP_REQUIRE(p, SHP_ERR_INVALID_ARG, "prover_profile: null prover");
