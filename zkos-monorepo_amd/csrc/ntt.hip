@@ -150,7 +150,9 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
             go = ((size_t)hi << (s + p.lo_bits)) | ((size_t)kp << p.lo_bits) | lo;
             uint64_t et = ((uint64_t)kp * lo) << hi_bits;
             if (et) {
-                Fr tw = gload(p.tw_hi + (et >> p.h)) * gload(p.tw_lo + (et & ((1u << p.h) - 1)));
+                // domains up to 2^18 keep every power in one (L2-resident) table: one product instead of two
+                Fr tw = gload(p.tw_lo + (et & ((1u << p.h) - 1)));
+                if (p.h < p.log_n) tw = gload(p.tw_hi + (et >> p.h)) * tw;
                 val = val * tw;
             }
         } else {
@@ -232,7 +234,7 @@ const NttTables& ntt_tables_for(shp_ctx* ctx, uint32_t log_n) {
     if (it != ctx->ntt_tables.end()) return it->second;
     NttTables t;
     t.log_n = log_n;
-    t.h = (log_n + 1) / 2;
+    t.h = log_n <= 18 ? log_n : (log_n + 1) / 2;
     Fr w = fr_root_of_unity(log_n);
     Fr wi = Fr::inv(w);
     t.lo[0] = upload_powers(w, (size_t)1 << t.h);
