@@ -153,6 +153,10 @@ int32_t shp_srs_from_parts(shp_ctx* ctx, uint32_t k, const void* h_g, const void
  * with the KNOWN trapdoor tau (32-byte LE canonical): g[i] = tau^i G, g_lagrange by group FFT.  For
  * tests and benchmarks only -- the reference's real k=13 ptau file is not shipped. No G2 part. */
 int32_t shp_srs_synthetic(shp_ctx* ctx, uint32_t k, const uint8_t tau_le32[32], shp_srs** out);
+/* Params::downsize(k) (/root/reference/crates/shielder-cli/src/shielder_ops/pk.rs:110; the step
+ * generate_keys_with_min_k applies once the circuit's minimal k is known): a NEW SRS with the first
+ * 2^k powers, g_lagrange re-derived on the GPU for the smaller domain, the same G2 elements. */
+int32_t shp_srs_downsize(const shp_srs* srs, uint32_t k, shp_srs** out);
 int32_t shp_srs_destroy(shp_srs* srs);
 int32_t shp_srs_k(const shp_srs* srs, uint32_t* k);
 /* copies of the tables / G2 elements back to the host (Params::get_g, g2, s_g2) */

