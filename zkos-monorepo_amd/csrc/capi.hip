@@ -174,6 +174,8 @@ int32_t shp_ctx_create(int32_t device, shp_ctx** out) {
                     "no HIP device available: libshielder_hip has no CPU fallback");
         SHP_REQUIRE(device >= 0 && device < n, SHP_ERR_INVALID_ARG, "ctx_create: device index out of range");
         SHP_HIP(hipSetDevice(device));
+        if (const char* e = getenv("SHP_BLOCKING_SYNC"))     // experiment: sleeping instead of spinning waits
+            if (*e == '1') fprintf(stderr, "[shp] blocking sync: %d\n", (int)hipSetDeviceFlags(hipDeviceScheduleBlockingSync));
         hipDeviceProp_t prop;
         SHP_HIP(hipGetDeviceProperties(&prop, device));
         std::unique_ptr<shp_ctx> c(new shp_ctx);

@@ -71,6 +71,29 @@ struct DevBuf {
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// growable page-locked host staging buffer: asynchronous copies to or from pageable memory go through the
+// runtime's own staging path, which serialises the streams of concurrent proving lanes
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) SHP_HIP(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + (bytes >> 2) + 256;
+        SHP_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 static inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace shp

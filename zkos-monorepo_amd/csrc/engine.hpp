@@ -63,13 +63,12 @@ struct MsmRows { uint32_t prefix, tail_start, tail_count; };
 struct MsmWorkspace {
     KernelTimers* timers = nullptr;
     DevBuf cnt, start, entries, pf, pl, buckets, out, wg_hist;
-    std::vector<G1X> h_out;
-    std::vector<uint32_t> h_totals;
+    PinnedBuf h_out, h_totals;             // G1X sums / per-MSM entry counts, read back after each run
     uint64_t last_adds = 0, last_bytes = 0;
     uint64_t min_waves = 0;     // direct mode: waves a launch should have before chains get longer (0 = default)
     void release() {
         cnt.release(); start.release(); entries.release(); pf.release(); pl.release(); buckets.release(); out.release();
-        wg_hist.release();
+        wg_hist.release(); h_out.release(); h_totals.release();
     }
 };
 

@@ -550,13 +550,18 @@ struct alignas(16) Fp {
         for (int i = 0; i < 8; i++) r3.l[i] = PR::r3(i);
         x = mul(x, r3);
         const uint32_t k1 = k < 256 ? k : 256, k2 = k - k1;
-        Fp c = zero();
-        c.l[(256 - k1) >> 5] = 1u << ((256 - k1) & 31);
+        // one-bit constants 2^e built limb by limb (a dynamic limb index would cost the kernel a scratch segment)
+        auto pow2 = [](uint32_t e) {
+            Fp c;
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) c.l[i] = (e >> 5) == i ? 1u << (e & 31) : 0u;
+            return c;
+        };
+        Fp c = pow2(256 - k1);
         if (k1 == 0) c = one();                            // unreachable for a != 0 (k >= 254)
         x = mul(x, c);
         if (k2) {
-            c = zero();
-            c.l[(256 - k2) >> 5] = 1u << ((256 - k2) & 31);
+            c = pow2(256 - k2);
             x = mul(x, c);
         }
         return x;

@@ -46,12 +46,38 @@ __device__ __forceinline__ Fr load_fr(const Fr* p) {
     return r;
 }
 
-__device__ __forceinline__ uint32_t raw_bits(const Fr& raw, uint32_t bitpos, uint32_t c) {
-    uint32_t limb = bitpos >> 5, off = bitpos & 31;
-    if (limb > 7) return 0;
-    uint64_t v = raw.l[limb];
-    if (limb < 7) v |= (uint64_t)raw.l[limb + 1] << 32;
-    return (uint32_t)((v >> off) & ((1u << c) - 1));
+// Digits are taken from the low end of a value that is shifted right window by window: every limb index is a
+// compile-time constant.  (A dynamic index -- even written as a select chain, which LLVM folds back into an indexed
+// load -- puts the limbs in scratch memory, and a kernel with a private segment does not overlap with kernels of
+// other streams on this stack: 16 lanes of msm_direct ran at the rate of one)
+__device__ __forceinline__ void raw_shr_bits(Fr& r, uint32_t t) {     // 1 <= t <= 31
+#pragma unroll
+    for (int i = 0; i < 7; i++) r.l[i] = (r.l[i] >> t) | (r.l[i + 1] << (32 - t));
+    r.l[7] >>= t;
+}
+__device__ __forceinline__ void raw_shr_any(Fr& r, uint32_t s) {      // 0 <= s; >= 256 clears
+    if (s >= 256) { r = Fr::zero(); return; }
+    if (s & 128) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { r.l[i] = r.l[i + 4]; r.l[i + 4] = 0; }
+    }
+    if (s & 64) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) r.l[i] = r.l[i + 2];
+        r.l[6] = r.l[7] = 0;
+    }
+    if (s & 32) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) r.l[i] = r.l[i + 1];
+        r.l[7] = 0;
+    }
+    if (s & 31) raw_shr_bits(r, s & 31);
+}
+// the low c bits (c <= 16), then shift them out
+__device__ __forceinline__ uint32_t raw_pop_bits(Fr& r, uint32_t c) {
+    const uint32_t d = r.l[0] & ((1u << c) - 1);
+    raw_shr_bits(r, c);
+    return d;
 }
 
 // ---------------------------------------------------------------- table precompute
@@ -100,7 +126,7 @@ __global__ __launch_bounds__(DIG_THREADS) void msm_hist_kernel(const Fr* scalars
         if (raw.is_zero()) continue;
         uint32_t carry = 0;
         for (uint32_t w = 0; w < W; w++) {
-            uint32_t d = raw_bits(raw, w * c, c) + carry;
+            uint32_t d = raw_pop_bits(raw, c) + carry;
             uint32_t sign = 0;
             carry = 0;
             if (d > NB) {
@@ -635,9 +661,10 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
             }
             const uint32_t half = a.NB;
             // next non-zero digit at or after window w: (table slot, sign), slot == NB means none
+            raw_shr_any(raw, w0 * a.c);                // the group's first window at bit 0
             auto next_digit = [&](uint32_t& w, uint32_t& neg) -> size_t {
                 for (; w < w1; w++) {
-                    uint32_t d = raw_bits(raw, w * a.c, a.c);
+                    uint32_t d = raw_pop_bits(raw, a.c);
                     neg = 0;
                     if (w + 1 < a.W) {
                         neg = d < half;
@@ -782,7 +809,7 @@ static void msm_build(shp_ctx* ctx, const G1Affine* d_bases, size_t n, uint32_t 
 }
 
 // host normalisation of `batch` XYZZ sums with one shared inversion (Montgomery's trick over ZZZ)
-static void normalise_batch(const std::vector<G1X>& in, uint32_t batch, G1Affine* h_out) {
+static void normalise_batch(const G1X* in, uint32_t batch, G1Affine* h_out) {
     std::vector<Fq> pre(batch);
     Fq acc = Fq::one();
     for (uint32_t b = 0; b < batch; b++) {
@@ -849,11 +876,11 @@ static void msm_run_direct(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalar
                        ws.out.as<G1X>());
     tm->end(st);
     SHP_HIP(hipGetLastError());
-    ws.h_out.resize(total);
-    SHP_HIP(hipMemcpyAsync(ws.h_out.data(), ws.out.p, (size_t)total * sizeof(G1X), hipMemcpyDeviceToHost, st));
+    ws.h_out.reserve((size_t)total * sizeof(G1X));
+    SHP_HIP(hipMemcpyAsync(ws.h_out.p, ws.out.p, (size_t)total * sizeof(G1X), hipMemcpyDeviceToHost, st));
     SHP_HIP(hipStreamSynchronize(st));
     tm->collect();
-    normalise_batch(ws.h_out, total, h_out);
+    normalise_batch(ws.h_out.as<G1X>(), total, h_out);
     const uint64_t visited = (uint64_t)batch * visited0 + (uint64_t)batch2 * n_scalars;
     ws.last_adds = visited * W;                               // upper bound: one mixed add per non-zero digit
     ws.last_bytes = visited * 32 + (uint64_t)n_scalars * 64;
@@ -943,16 +970,16 @@ void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n
     }
     tm->end(st);
     SHP_HIP(hipGetLastError());
-    ws.h_out.resize(batch);
-    ws.h_totals.resize(batch);
-    SHP_HIP(hipMemcpyAsync(ws.h_out.data(), ws.out.p, (size_t)batch * sizeof(G1X), hipMemcpyDeviceToHost, st));
-    SHP_HIP(hipMemcpy2DAsync(ws.h_totals.data(), 4, start + NB + 1, (size_t)(NB + 2) * 4, 4, batch,
+    ws.h_out.reserve((size_t)batch * sizeof(G1X));
+    ws.h_totals.reserve((size_t)batch * 4);
+    SHP_HIP(hipMemcpyAsync(ws.h_out.p, ws.out.p, (size_t)batch * sizeof(G1X), hipMemcpyDeviceToHost, st));
+    SHP_HIP(hipMemcpy2DAsync(ws.h_totals.p, 4, start + NB + 1, (size_t)(NB + 2) * 4, 4, batch,
                              hipMemcpyDeviceToHost, st));
     SHP_HIP(hipStreamSynchronize(st));
     tm->collect();
-    normalise_batch(ws.h_out, batch, h_out);
+    normalise_batch(ws.h_out.as<G1X>(), batch, h_out);
     ws.last_adds = 0;
-    for (uint32_t b = 0; b < batch; b++) ws.last_adds += ws.h_totals[b];
+    for (uint32_t b = 0; b < batch; b++) ws.last_adds += ws.h_totals.as<uint32_t>()[b];
     ws.last_bytes = (uint64_t)batch * n_scalars * 32 + (uint64_t)n_scalars * 64;
 }
 

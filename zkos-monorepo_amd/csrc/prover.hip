@@ -535,7 +535,18 @@ struct shp_prover {
         owned.push_back(p);
         return (T*)p;
     }
+    // page-locked staging for every small host<->device copy of a proof (copies from pageable memory take the
+    // runtime's slow path and serialise concurrent lanes); bump-allocated, rewound at the start of each proof
+    PinnedBuf stage;
+    size_t stage_off = 0;
+    void* stage_alloc(size_t bytes) {
+        const size_t at = (stage_off + 63) & ~(size_t)63;
+        SHP_REQUIRE(at + bytes <= stage.cap, SHP_ERR_INTERNAL, "prover: staging arena exhausted");
+        stage_off = at + bytes;
+        return (uint8_t*)stage.p + at;
+    }
     ~shp_prover() {
+        stage.release();
         for (void* p : owned) (void)hipFree(p);
         msm_ws.release();
         if (h_grid) (void)hipHostFree(h_grid);
@@ -593,6 +604,7 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->ntt_tmp = pr->dalloc<Fr>((size_t)(NV + 1) * ne);
     pr->key = pr->dalloc<uint32_t>(8);
     pr->rank = pr->dalloc<uint32_t>((size_t)2 * L * n);
+    pr->stage.reserve((size_t)1 << 20);
     SHP_HIP(hipHostMalloc((void**)&pr->h_grid, (size_t)(P.num_advice + 1) * n * sizeof(Fr), hipHostMallocDefault));
     memset(pr->h_grid, 0, (size_t)(P.num_advice + 1) * n * sizeof(Fr));
     pr->sc_cnt = std::max<uint32_t>(S + L, MAX_POINTS);
@@ -709,6 +721,13 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     auto draw = [&]() { return fr_draw(key, ctr++); };
 
     PhaseClock pc;
+    pr->stage_off = 0;                                  // the previous proof's copies have all completed
+    auto h2d = [&](void* dst, const void* src, size_t bytes) {
+        if (!bytes) return;
+        void* sbuf = pr->stage_alloc(bytes);
+        memcpy(sbuf, src, bytes);
+        SHP_HIP(hipMemcpyAsync(dst, sbuf, bytes, hipMemcpyHostToDevice, st));
+    };
     // ---- P0/P1: witness, blinding rows, instance column
     std::vector<Fr> inputs(n_inputs);
     for (size_t i = 0; i < n_inputs; i++) {
@@ -740,7 +759,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     if (A) SHP_HIP(hipMemcpy2DAsync(V(0) + u, pitch, grid + u, pitch, (size_t)(n - u) * sizeof(Fr), A, hipMemcpyHostToDevice, st));
     if (!instances.empty())
         SHP_HIP(hipMemcpyAsync(V(I_INST), instcol, instances.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
-    SHP_HIP(hipMemcpyAsync(pr->key, key, 32, hipMemcpyHostToDevice, st));
+    h2d(pr->key, key, 32);
     Transcript tr(pk->vk_digest);
     for (auto& v : instances) tr.common_scalar(v);
     pc.mark("witness+upload");
@@ -803,7 +822,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
             for (uint32_t j = 0; j < 2 * nb; j++) hb.push_back(draw());   // permuted input rows, then table rows
             ctr += 2;                                                     // two (unused) commitment blinds
         }
-        SHP_HIP(hipMemcpyAsync(pr->blinds, hb.data(), hb.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
+        h2d(pr->blinds, hb.data(), hb.size() * sizeof(Fr));
         SHP_HIP(hipMemsetAsync(pr->err, 0, 16, st));
         uint32_t nt = std::min<uint32_t>(1024, n);
         // sorted input of lookup l at sort_out[2l], sorted table at sort_out[2l+1]
@@ -811,10 +830,10 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
                            (size_t)2 * n, u, n, pr->rank);
         hipLaunchKernelGGL(lookup_permute_kernel, dim3(L), dim3(nt), 0, st, pr->sort_out, pr->sort_out + n, (size_t)2 * n, u, n,
                            V(I_PIN), V(I_PIN + 1), (size_t)2 * n, pr->rep_scratch, pr->rank, pr->blinds, pr->err);
-        uint32_t herr = 0;
+        uint32_t* herr = (uint32_t*)pr->stage_alloc(4);  // read back with the commitments (the MSM run synchronises)
+        SHP_HIP(hipMemcpyAsync(herr, pr->err, 4, hipMemcpyDeviceToHost, st));
         msm_run_ws(srs->msm_gl, pr->msm_ws, V(I_PIN), n, n, 2 * L, pts.data(), st);
-        SHP_HIP(hipMemcpy(&herr, pr->err, 4, hipMemcpyDeviceToHost));
-        SHP_REQUIRE(herr == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
+        SHP_REQUIRE(*herr == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
         for (uint32_t i = 0; i < 2 * L; i++) tr.write_point(pts[i].x, pts[i].y);
     }
     pc.mark("lookup");
@@ -839,7 +858,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         for (uint32_t j = 0; j < bf; j++) hb.push_back(draw());
         ctr += 1;
     }
-    if (!hb.empty()) SHP_HIP(hipMemcpyAsync(pr->blinds, hb.data(), hb.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
+    h2d(pr->blinds, hb.data(), hb.size() * sizeof(Fr));
     pr->timers.begin(KID_GRAND_PRODUCT, st);
     if (S + L) {                                           // a plan may have neither a permutation nor a lookup
         product_scans(pr->num, pr->den, S + L);
@@ -922,7 +941,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         pt_index[r] = (uint32_t)i;
         points[i] = x * (r >= 0 ? Fr::pow_u64(pk->omega, (uint64_t)r) : Fr::pow_u64(pk->omega_inv, (uint64_t)(-r)));
     }
-    SHP_HIP(hipMemcpyAsync(pr->points, points.data(), points.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
+    h2d(pr->points, points.data(), points.size() * sizeof(Fr));
     {
         uint32_t per = 8;
         hipLaunchKernelGGL(powers_kernel, dim3(ceil_div(ceil_div(n, per), 256), (uint32_t)points.size()), dim3(256), 0, st,
@@ -965,15 +984,15 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     const size_t n_proof_evals = jobs.size();
     add_job({7, 0}, 0);
     SHP_REQUIRE(jobs.size() <= 512, SHP_ERR_INVALID_ARG, "prove: too many evaluations");
-    SHP_HIP(hipMemcpyAsync(pr->jobs, jobs.data(), jobs.size() * sizeof(EvalJob), hipMemcpyHostToDevice, st));
+    h2d(pr->jobs, jobs.data(), jobs.size() * sizeof(EvalJob));
     hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)jobs.size()), dim3(256), 0, st, pr->jobs, pr->pw, n, pr->evals);
     // Lagrange values of hx and the random polynomial for the evaluation-form opening
     SHP_HIP(hipMemcpyAsync(pr->lag2, pr->hx, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     SHP_HIP(hipMemcpyAsync(pr->lag2 + n, pr->rand_poly, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     NttOpts fwd;
     ntt_launch(ctx, pr->lag2, pr->lag2, k, 2, fwd, st, pr->ntt_tmp);
-    std::vector<Fr> evals(jobs.size());
-    SHP_HIP(hipMemcpyAsync(evals.data(), pr->evals, jobs.size() * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    const Fr* evals = (const Fr*)pr->stage_alloc(jobs.size() * sizeof(Fr));
+    SHP_HIP(hipMemcpyAsync((void*)evals, pr->evals, jobs.size() * sizeof(Fr), hipMemcpyDeviceToHost, st));
     SHP_HIP(hipStreamSynchronize(st));
     std::map<std::pair<PolyKey, int32_t>, Fr> ev;
     for (size_t i = 0; i < jobs.size(); i++) ev[job_key[i]] = evals[i];
@@ -1025,8 +1044,8 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         nu_pow = nu_pow * nu;
     }
     sa.f = pr->fsets; sa.dinv = pr->dinv; sa.omegas = pk->omegas;
-    SHP_HIP(hipMemcpyAsync(pr->lin, lin.data(), lin.size() * sizeof(LincombArgs), hipMemcpyHostToDevice, st));
-    SHP_HIP(hipMemcpyAsync(pr->shp_args, &sa, sizeof(sa), hipMemcpyHostToDevice, st));
+    h2d(pr->lin, lin.data(), lin.size() * sizeof(LincombArgs));
+    h2d(pr->shp_args, &sa, sizeof(sa));
     hipLaunchKernelGGL(lincomb_kernel, dim3(ceil_div(n, 256), (uint32_t)sets.size()), dim3(256), 0, st, pr->lin, n, pr->fsets);
     hipLaunchKernelGGL(point_diff_kernel, dim3(ceil_div(n, 256), (uint32_t)points.size()), dim3(256), 0, st, pk->omegas,
                        pr->points, n, pr->pdiff);
@@ -1059,8 +1078,8 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     sa.c1 = zt * d0inv;
     sa.w = pr->wvals;
     sa.minv = pr->mdiff + n;
-    SHP_HIP(hipMemcpyAsync(pr->shp_args, &sa, sizeof(sa), hipMemcpyHostToDevice, st));
-    SHP_HIP(hipMemcpyAsync(pr->points, &mu, sizeof(Fr), hipMemcpyHostToDevice, st));
+    h2d(pr->shp_args, &sa, sizeof(sa));
+    h2d(pr->points, &mu, sizeof(Fr));
     hipLaunchKernelGGL(point_diff_kernel, dim3(ceil_div(n, 256), 1), dim3(256), 0, st, pk->omegas, pr->points, n, pr->mdiff);
     batch_invert(pr->mdiff, pr->mdiff + n, 1);
     hipLaunchKernelGGL(shplonk_wp_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals + n);
