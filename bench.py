@@ -198,6 +198,18 @@ def main():
                 traffic = ent["fetch_bytes_per_launch_x2corr"] + ent["write_bytes_per_launch"]
         except OSError:
             pass
+        # VALU issue utilisation of the whole proof: wave-instructions per proof from the committed PMC pass
+        # (rocprofv3 --pmc SQ_INSTS_VALU over tools/prove_loop.py --throughput, profiles/README.md), 4 cycles each on
+        # one of 1024 SIMDs at 2.4 GHz, against the per-GPU proof rate measured here
+        valu = None
+        try:
+            pv = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_valu_prove.json")))
+            wi = pv["valu_wave_instructions_per_proof"]
+            ideal_s = wi * 4.0 / (1024 * 2.4e9)
+            valu = {"wave_instructions_per_proof": wi, "ideal_us_per_proof": 1e6 * ideal_s,
+                    "issue_frac": ideal_s * (total_proofs / elapsed / n_gpus)}
+        except (OSError, KeyError):
+            pass
         out = {
             "metric": "Shielder proofs/sec (whole node), 2^13 withdraw-shaped circuit",
             "value": total_proofs / elapsed,
@@ -222,7 +234,7 @@ def main():
                          "note": "k=13 kernels are bound by the 32-bit integer ALU, not by HBM (DESIGN.md section 3); the direct-table "
                                  "MSM deliberately gathers one 64 B table entry per non-zero digit (traffic >> algorithmic bytes) "
                                  "to remove all bucket arithmetic",
-                         "alu": {"fr_mul_ceiling_per_s": ctx.fr_mul_rate(2048),
+                         "alu": {"valu": valu, "fr_mul_ceiling_per_s": ctx.fr_mul_rate(2048),
                                  "unit": "254-bit Montgomery products/s, every CU busy (tools/ubench, shp_diag_fr_mul_rate)"}},
             "kernel_ms_per_proof": {k_: v[1] / max(1, a.steps * proofs_per_step) for k_, v in sorted(prof.items())},
         }

@@ -550,7 +550,7 @@ struct alignas(16) Fp {
         for (int i = 0; i < 8; i++) r3.l[i] = PR::r3(i);
         x = mul(x, r3);
         const uint32_t k1 = k < 256 ? k : 256, k2 = k - k1;
-        // one-bit constants 2^e built limb by limb (a dynamic limb index would cost the kernel a scratch segment)
+        // one-bit constants 2^e built limb by limb (a dynamic limb index would put the value in scratch memory)
         auto pow2 = [](uint32_t e) {
             Fp c;
 #pragma unroll

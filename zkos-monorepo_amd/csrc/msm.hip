@@ -48,8 +48,7 @@ __device__ __forceinline__ Fr load_fr(const Fr* p) {
 
 // Digits are taken from the low end of a value that is shifted right window by window: every limb index is a
 // compile-time constant.  (A dynamic index -- even written as a select chain, which LLVM folds back into an indexed
-// load -- puts the limbs in scratch memory, and a kernel with a private segment does not overlap with kernels of
-// other streams on this stack: 16 lanes of msm_direct ran at the rate of one)
+// load -- puts the limbs in scratch memory: a private segment for the kernel and VMEM round trips on the digit path.)
 __device__ __forceinline__ void raw_shr_bits(Fr& r, uint32_t t) {     // 1 <= t <= 31
 #pragma unroll
     for (int i = 0; i < 7; i++) r.l[i] = (r.l[i] >> t) | (r.l[i + 1] << (32 - t));
