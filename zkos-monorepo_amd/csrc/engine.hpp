@@ -64,11 +64,14 @@ struct MsmWorkspace {
     KernelTimers* timers = nullptr;
     DevBuf cnt, start, entries, pf, pl, buckets, out, wg_hist;
     PinnedBuf h_out, h_totals;             // G1X sums / per-MSM entry counts, read back after each run
+    DevBuf segs;                           // direct mode: the launch's segment table
+    PinnedBuf h_segs;
+    std::vector<G1Affine> h_aff;
     uint64_t last_adds = 0, last_bytes = 0;
     uint64_t min_waves = 0;     // direct mode: waves a launch should have before chains get longer (0 = default)
     void release() {
         cnt.release(); start.release(); entries.release(); pf.release(); pl.release(); buckets.release(); out.release();
-        wg_hist.release(); h_out.release(); h_totals.release();
+        wg_hist.release(); h_out.release(); h_totals.release(); segs.release(); h_segs.release();
     }
 };
 
@@ -103,6 +106,19 @@ struct shp_srs {
     bool has_g2 = false;
 };
 
+// one entry of a multi-job direct-table launch: `batch` MSMs over m's bases, scalar column b at scalars + b * stride
+namespace shp {
+constexpr uint32_t MSM_MAX_JOBS = 64;
+struct MsmJob {
+    shp_msm* m;
+    const Fr* scalars;
+    size_t stride;
+    uint32_t batch;
+    MsmRows rows;
+    G1Affine* h_out;      // batch affine points
+};
+}  // namespace shp
+void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& ws, hipStream_t st);
 // `batch` MSMs over the plan's bases; synchronises `st` and normalises on the host
 void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const shp::Fr* d_scalars, size_t n_scalars, size_t stride,
                 uint32_t batch, shp::G1Affine* h_out, hipStream_t st);

@@ -20,6 +20,7 @@
 //   * sum_b b * B_b: per-thread running sums over g buckets, an LDS suffix scan and a tree.
 //   * The handful of final XYZZ sums are normalised on the host (needed there anyway for the
 //     Keccak transcript).
+#include <string.h>
 #include <algorithm>
 #include <mutex>
 #include <stdlib.h>
@@ -454,21 +455,28 @@ __global__ __launch_bounds__(64) void msm_multiples_kernel(const G1Affine* __res
     }
 }
 
-struct DirectArgs {
-    // up to two segments of the batch, each over its own multiples table (same n, c, W):
-    // MSM m < split uses segment 0, the rest segment 1
-    const G1Affine* mult[2];
-    const Fr* scalars[2];
-    size_t stride[2];
-    uint32_t split;
-    // scalars a segment actually visits: rows [0, prefix) and [tail_start, tail_start + tail_count)
+// One launch serves any number of jobs (segments): `batch` MSMs each, over its own multiples table and scalar
+// columns, all tables of one shape (n, c, W).  The segment table lives in device memory; workgroup -> segment by
+// binary search over wg_base (a by-value array indexed dynamically would be copied to scratch).
+struct DirectSeg {
+    const G1Affine* mult;
+    const Fr* scalars;
+    uint64_t stride;
+    // rows a segment actually visits: [0, prefix) and [tail_start, tail_start + tail_count)
     // (a witness column is zero between its assigned rows and its blinding rows)
-    uint32_t prefix[2], tail_start[2], tail_count[2];
-    uint32_t gx[2];     // 256-row blocks per MSM of each segment
+    uint32_t prefix, tail_start, tail_count;
+    uint32_t gx;          // 256-row blocks per MSM
+    uint32_t wg_base;     // first blockIdx.x of the segment
+    uint32_t msm_base;    // index of its first MSM in the launch
+    uint64_t part_base;   // its partials: [batch][gy][gx] from here
+};
+struct DirectArgs {
+    const DirectSeg* segs;
+    uint32_t n_segs;
     size_t n_table;
     uint32_t c, W, NB, T;
     Fr bias;
-    G1X* partials;      // [batch][gridDim.y * gridDim.x]
+    G1X* partials;
 };
 
 __device__ __forceinline__ G1Affine load_affine(const G1Affine* p) {
@@ -632,24 +640,28 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
     return r;
 }
 
-// lane <-> scalar i, blockIdx.y <-> group of T windows, blockIdx.x <-> (MSM of the batch, 256-row block):
+// lane <-> scalar i, blockIdx.y <-> group of T windows, blockIdx.x <-> (segment, MSM of its batch, 256-row block):
 // only row blocks a segment visits are launched (an empty workgroup still costs ~0.1 us of dispatch)
 __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a) {
     __shared__ uint32_t sh[COOP_LDS_WORDS];
-    const uint32_t seg = blockIdx.x >= a.split * a.gx[0] ? 1u : 0u;
-    const uint32_t bx = blockIdx.x - (seg ? a.split * a.gx[0] : 0u);
-    const uint32_t m = bx / a.gx[seg], blk = bx % a.gx[seg];
+    uint32_t lo = 0, hi = a.n_segs;                            // last segment with wg_base <= blockIdx.x
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.segs[mid].wg_base <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const DirectSeg sg = a.segs[lo];
+    const uint32_t bx = blockIdx.x - sg.wg_base;
+    const uint32_t m = bx / sg.gx, blk = bx % sg.gx;
     const uint32_t lane = blk * MSM_THREADS + threadIdx.x;
-    const uint32_t visited = a.prefix[seg] + a.tail_count[seg];
-    // partials of MSM z: [gy][gx[seg]] at the segment's base
-    const size_t part = (seg ? (size_t)a.split * a.gx[0] * gridDim.y : 0) + ((size_t)m * gridDim.y + blockIdx.y) * a.gx[seg] + blk;
-    const size_t i = lane < a.prefix[seg] ? lane : (size_t)a.tail_start[seg] + (lane - a.prefix[seg]);
-    const G1Affine* __restrict__ mult = a.mult[seg];
+    const uint32_t visited = sg.prefix + sg.tail_count;
+    const size_t part = sg.part_base + ((size_t)m * gridDim.y + blockIdx.y) * sg.gx + blk;
+    const size_t i = lane < sg.prefix ? lane : (size_t)sg.tail_start + (lane - sg.prefix);
+    const G1Affine* __restrict__ mult = sg.mult;
     const uint32_t w0 = blockIdx.y * a.T;
     const uint32_t w1 = w0 + a.T < a.W ? w0 + a.T : a.W;
     G1X acc = G1X::inf();
     if (lane < visited) {
-        Fr raw = load_fr(a.scalars[seg] + (size_t)m * a.stride[seg] + i).to_raw();
+        Fr raw = load_fr(sg.scalars + (size_t)m * sg.stride + i).to_raw();
         if (!raw.is_zero()) {
             uint64_t cy = 0;
 #pragma unroll
@@ -695,17 +707,23 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
     if (threadIdx.x == 0) a.partials[part] = acc;
 }
 
-// one workgroup per MSM: sum of its partials (P0 each for the first `split` MSMs, P1 for the rest)
-__global__ __launch_bounds__(MSM_THREADS) void msm_direct_final_kernel(const G1X* partials, uint32_t split, uint32_t P0,
-                                                                       uint32_t P1, G1X* out) {
+// one workgroup per MSM of the launch: sum of its gx * gy partials
+__global__ __launch_bounds__(MSM_THREADS) void msm_direct_final_kernel(const DirectSeg* segs, uint32_t n_segs, uint32_t gy,
+                                                                       const G1X* partials, G1X* out) {
     __shared__ uint32_t sh[COOP_LDS_WORDS];
-    const uint32_t m = blockIdx.x;
-    const uint32_t P = m < split ? P0 : P1;
-    const G1X* p = partials + (m < split ? (size_t)m * P0 : (size_t)split * P0 + (size_t)(m - split) * P1);
+    const uint32_t g = blockIdx.x;
+    uint32_t lo = 0, hi = n_segs;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (segs[mid].msm_base <= g) lo = mid; else hi = mid;
+    }
+    const DirectSeg sg = segs[lo];
+    const uint32_t P = sg.gx * gy;
+    const G1X* p = partials + sg.part_base + (size_t)(g - sg.msm_base) * P;
     G1X acc = G1X::inf();
     for (uint32_t j = threadIdx.x; j < P; j += MSM_THREADS) acc = g1_add(acc, p[j]);
     acc = block_sum_256(acc, sh, P < MSM_THREADS ? P : MSM_THREADS);
-    if (threadIdx.x == 0) out[m] = acc;
+    if (threadIdx.x == 0) out[g] = acc;
 }
 
 }  // namespace shp
@@ -827,62 +845,88 @@ static void normalise_batch(const G1X* in, uint32_t batch, G1Affine* h_out) {
     }
 }
 
-static void msm_run_direct(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n_scalars, size_t stride,
-                           uint32_t batch, G1Affine* h_out, hipStream_t st, shp_msm* m2 = nullptr,
-                           const Fr* d_scalars2 = nullptr, size_t stride2 = 0, uint32_t batch2 = 0,
-                           const shp::MsmRows* rows = nullptr) {
-    const uint32_t W = m->W, total = batch + batch2;
-    // segment 0 may visit only its assigned rows; segment 1 is always dense
-    shp::MsmRows r0{(uint32_t)n_scalars, 0, 0};
-    if (rows) {
-        SHP_REQUIRE((size_t)rows->prefix <= rows->tail_start && (size_t)rows->tail_start + rows->tail_count <= n_scalars,
+// All jobs in ONE launch of msm_direct_kernel + one of the final sums; synchronises `st`.
+void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& ws, hipStream_t st) {
+    SHP_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= shp::MSM_MAX_JOBS, SHP_ERR_INVALID_ARG, "msm: bad job list");
+    const shp_msm* m0 = jobs[0].m;
+    SHP_REQUIRE(m0 && m0->direct, SHP_ERR_INVALID_ARG, "msm: job list needs direct-table plans");
+    const uint32_t W = m0->W;
+    std::vector<DirectSeg> segs(n_jobs);
+    uint64_t busy_wgs = 0, total = 0, visited_all = 0;
+    for (uint32_t k = 0; k < n_jobs; k++) {
+        const shp::MsmJob& jb = jobs[k];
+        SHP_REQUIRE(jb.m && jb.m->direct && jb.m->n == m0->n && jb.m->c == m0->c && jb.m->W == W, SHP_ERR_INVALID_ARG,
+                    "msm: the jobs of one launch need plans of the same shape");
+        SHP_REQUIRE(jb.scalars && jb.h_out && jb.batch, SHP_ERR_INVALID_ARG, "msm: bad job");
+        SHP_REQUIRE(jb.rows.prefix <= jb.m->n && (size_t)jb.rows.tail_start + jb.rows.tail_count <= jb.m->n &&
+                        (jb.rows.tail_count == 0 || jb.rows.prefix <= jb.rows.tail_start),
                     SHP_ERR_INVALID_ARG, "msm: bad row ranges");
-        r0 = *rows;
+        const uint32_t visited = jb.rows.prefix + jb.rows.tail_count;
+        DirectSeg& sg = segs[k];
+        sg.mult = jb.m->d_mult; sg.scalars = jb.scalars; sg.stride = jb.stride;
+        sg.prefix = jb.rows.prefix; sg.tail_start = jb.rows.tail_start; sg.tail_count = jb.rows.tail_count;
+        sg.gx = ceil_div(std::max<uint32_t>(visited, 1), MSM_THREADS);
+        sg.wg_base = (uint32_t)busy_wgs;
+        sg.msm_base = (uint32_t)total;
+        busy_wgs += (uint64_t)sg.gx * jb.batch;
+        total += jb.batch;
+        visited_all += (uint64_t)visited * jb.batch;
     }
-    const uint32_t visited0 = r0.prefix + r0.tail_count;
-    if (batch2) SHP_REQUIRE(m2 && m2->direct && m2->n == m->n && m2->c == m->c && m2->W == W, SHP_ERR_INVALID_ARG,
-                            "msm: the two segments need plans of the same shape");
-    const uint32_t gx0 = ceil_div(std::max<uint32_t>(visited0, 1), MSM_THREADS), gx1 = ceil_div(n_scalars, MSM_THREADS);
-    const uint64_t busy_wgs = (uint64_t)gx0 * batch + (uint64_t)gx1 * batch2;
+    SHP_REQUIRE(busy_wgs < (1ull << 31), SHP_ERR_INVALID_ARG, "msm: launch too large");
     // T windows per lane: all of them when the launch fills the chip anyway (least tree overhead),
     // shorter chains for small launches (latency)
     static const uint64_t base_waves = getenv("SHP_MSM_MIN_WAVES") ? (uint64_t)atol(getenv("SHP_MSM_MIN_WAVES")) : 1024;
-    static const uint64_t big_waves = getenv("SHP_MSM_BIG_WAVES") ? (uint64_t)atol(getenv("SHP_MSM_BIG_WAVES")) : 1024;
-    const uint64_t min_waves = ws.min_waves ? ws.min_waves : total >= 8 ? big_waves : base_waves;
+    const uint64_t min_waves = ws.min_waves ? ws.min_waves : base_waves;
     const uint32_t cand[6] = {W, (W + 1) / 2, 8, 4, 2, 1};
     uint32_t T = 1;
     for (uint32_t t : cand)
         if (t <= W && busy_wgs * (MSM_THREADS / 64) * ceil_div(W, t) >= min_waves) { T = t; break; }
     const uint32_t gy = ceil_div(W, T);
-    const uint32_t P0 = gx0 * gy, P1 = gx1 * gy;
-    ws.pf.reserve(((size_t)batch * P0 + (size_t)batch2 * P1) * sizeof(G1X));
-    ws.out.reserve((size_t)total * sizeof(G1X));
+    uint64_t parts = 0;
+    for (uint32_t k = 0; k < n_jobs; k++) {
+        segs[k].part_base = parts;
+        parts += (uint64_t)jobs[k].batch * segs[k].gx * gy;
+    }
+    ws.pf.reserve(parts * sizeof(G1X));
+    ws.out.reserve(total * sizeof(G1X));
+    ws.segs.reserve(n_jobs * sizeof(DirectSeg));
+    ws.h_segs.reserve(n_jobs * sizeof(DirectSeg));
+    memcpy(ws.h_segs.p, segs.data(), n_jobs * sizeof(DirectSeg));
+    SHP_HIP(hipMemcpyAsync(ws.segs.p, ws.h_segs.p, n_jobs * sizeof(DirectSeg), hipMemcpyHostToDevice, st));
     DirectArgs a;
-    a.mult[0] = m->d_mult; a.scalars[0] = d_scalars; a.stride[0] = stride;
-    a.mult[1] = m2 ? m2->d_mult : m->d_mult; a.scalars[1] = d_scalars2; a.stride[1] = stride2;
-    a.split = batch;
-    a.prefix[0] = r0.prefix; a.tail_start[0] = r0.tail_start; a.tail_count[0] = r0.tail_count;
-    a.prefix[1] = (uint32_t)n_scalars; a.tail_start[1] = 0; a.tail_count[1] = 0;
-    a.gx[0] = gx0; a.gx[1] = gx1;
-    a.n_table = m->n;
-    a.c = m->c; a.W = W; a.NB = m->NB; a.T = T; a.bias = m->bias; a.partials = ws.pf.as<G1X>();
+    a.segs = ws.segs.as<DirectSeg>(); a.n_segs = n_jobs;
+    a.n_table = m0->n;
+    a.c = m0->c; a.W = W; a.NB = m0->NB; a.T = T; a.bias = m0->bias; a.partials = ws.pf.as<G1X>();
     KernelTimers none, *tm = ws.timers ? ws.timers : &none;
     tm->begin(KID_MSM_DIRECT, st);
     hipLaunchKernelGGL(msm_direct_kernel, dim3((uint32_t)busy_wgs, gy), dim3(MSM_THREADS), 0, st, a);
     tm->end(st);
     tm->begin(KID_MSM_DIRECT_FINAL, st);
-    hipLaunchKernelGGL(msm_direct_final_kernel, dim3(total), dim3(MSM_THREADS), 0, st, ws.pf.as<G1X>(), batch, P0, P1,
-                       ws.out.as<G1X>());
+    hipLaunchKernelGGL(msm_direct_final_kernel, dim3((uint32_t)total), dim3(MSM_THREADS), 0, st, a.segs, n_jobs, gy,
+                       ws.pf.as<G1X>(), ws.out.as<G1X>());
     tm->end(st);
     SHP_HIP(hipGetLastError());
-    ws.h_out.reserve((size_t)total * sizeof(G1X));
-    SHP_HIP(hipMemcpyAsync(ws.h_out.p, ws.out.p, (size_t)total * sizeof(G1X), hipMemcpyDeviceToHost, st));
+    ws.h_out.reserve(total * sizeof(G1X));
+    SHP_HIP(hipMemcpyAsync(ws.h_out.p, ws.out.p, total * sizeof(G1X), hipMemcpyDeviceToHost, st));
     SHP_HIP(hipStreamSynchronize(st));
     tm->collect();
-    normalise_batch(ws.h_out.as<G1X>(), total, h_out);
-    const uint64_t visited = (uint64_t)batch * visited0 + (uint64_t)batch2 * n_scalars;
-    ws.last_adds = visited * W;                               // upper bound: one mixed add per non-zero digit
-    ws.last_bytes = visited * 32 + (uint64_t)n_scalars * 64;
+    ws.h_aff.resize(total);
+    normalise_batch(ws.h_out.as<G1X>(), (uint32_t)total, ws.h_aff.data());
+    for (uint32_t k = 0; k < n_jobs; k++)
+        memcpy(jobs[k].h_out, ws.h_aff.data() + segs[k].msm_base, (size_t)jobs[k].batch * sizeof(G1Affine));
+    ws.last_adds = visited_all * W;                           // upper bound: one mixed add per non-zero digit
+    ws.last_bytes = visited_all * 32 + (uint64_t)m0->n * 64;
+}
+
+static void msm_run_direct(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n_scalars, size_t stride,
+                           uint32_t batch, G1Affine* h_out, hipStream_t st, shp_msm* m2 = nullptr,
+                           const Fr* d_scalars2 = nullptr, size_t stride2 = 0, uint32_t batch2 = 0,
+                           const shp::MsmRows* rows = nullptr) {
+    shp::MsmJob jobs[2];
+    jobs[0] = shp::MsmJob{m, d_scalars, stride, batch, rows ? *rows : shp::MsmRows{(uint32_t)n_scalars, 0, 0}, h_out};
+    if (rows) SHP_REQUIRE((size_t)rows->tail_start + rows->tail_count <= n_scalars, SHP_ERR_INVALID_ARG, "msm: bad row ranges");
+    if (batch2) jobs[1] = shp::MsmJob{m2, d_scalars2, stride2, batch2, shp::MsmRows{(uint32_t)n_scalars, 0, 0}, h_out + batch};
+    msm_run_jobs(jobs, batch2 ? 2 : 1, ws, st);
 }
 
 // `batch` MSMs over m and `batch2` over m2 (both direct-table plans of one shape) in ONE launch;
