@@ -97,3 +97,13 @@ struct PinnedBuf {
 static inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace shp
+
+// Cross-lane MSM combiner of a proving pool (implemented in msm.hip, owned by the pool): opaque here
+namespace shp {
+struct MsmCombiner;
+MsmCombiner* msm_combiner_create(int device);
+void msm_combiner_destroy(MsmCombiner* c);
+}  // namespace shp
+// internal (not part of the C ABI): commitments of this lane go through the pool's combiner; `profile_owner` lanes
+// report the combiner's kernel timers with their own (shp_prover_profile_read)
+void shp_prover_attach_combiner(shp_prover* p, shp::MsmCombiner* c, bool profile_owner);

@@ -1,5 +1,10 @@
 // Internal interfaces shared by the kernel files and the prover (not part of the C ABI).
 #pragma once
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
 #include "ctx.hpp"
 #include "curve.cuh"
 
@@ -119,6 +124,37 @@ struct MsmJob {
 };
 }  // namespace shp
 void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& ws, hipStream_t st);
+
+namespace shp {
+// A proving pool's lanes reach their commitment phases at different times; each phase alone is a launch of a few
+// hundred waves that cannot fill 1024 SIMDs.  The combiner takes whatever requests are queued when its previous
+// launch has finished (natural batching: no waiting window, a lone lane pays nothing) and serves them with ONE
+// msm_direct launch + one final-sum launch + one read-back on its own stream.  Lanes hand over device pointers and
+// an event recorded on their stream; they sleep until their points are back.
+struct MsmCombiner {
+    struct Req {
+        const MsmJob* jobs;
+        uint32_t n_jobs;
+        hipEvent_t ready;
+        bool done = false;
+        int32_t status = SHP_OK;
+        std::string err;
+    };
+    int device = 0;
+    hipStream_t st = nullptr;
+    MsmWorkspace ws;
+    KernelTimers timers;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv_req, cv_done;
+    std::deque<Req*> q;
+    bool stop = false;
+    uint64_t launches = 0, requests = 0;
+    // blocks until the jobs' points are in their h_out; everything queued on lane_stream so far has completed then
+    void run(const MsmJob* jobs, uint32_t n_jobs, hipStream_t lane_stream, hipEvent_t ready);
+    void loop();
+};
+}  // namespace shp
 // `batch` MSMs over the plan's bases; synchronises `st` and normalises on the host
 void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const shp::Fr* d_scalars, size_t n_scalars, size_t stride,
                 uint32_t batch, shp::G1Affine* h_out, hipStream_t st);

@@ -918,6 +918,93 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
     ws.last_bytes = visited_all * 32 + (uint64_t)m0->n * 64;
 }
 
+// ---------------------------------------------------------------- cross-lane combiner (engine.hpp)
+void shp::MsmCombiner::run(const MsmJob* jobs, uint32_t n_jobs, hipStream_t lane_stream, hipEvent_t ready) {
+    Req r;
+    r.jobs = jobs;
+    r.n_jobs = n_jobs;
+    r.ready = ready;
+    SHP_HIP(hipEventRecord(ready, lane_stream));
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        SHP_REQUIRE(!stop, SHP_ERR_INTERNAL, "msm combiner: shutting down");
+        q.push_back(&r);
+        cv_req.notify_one();
+        cv_done.wait(lk, [&] { return r.done; });
+    }
+    if (r.status != SHP_OK) throw shp::Error(r.status, r.err);
+}
+
+void shp::MsmCombiner::loop() {
+    (void)hipSetDevice(device);
+    std::vector<Req*> batch;
+    std::vector<MsmJob> all;
+    for (;;) {
+        batch.clear();
+        all.clear();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_req.wait(lk, [&] { return stop || !q.empty(); });
+            if (q.empty()) return;                                 // stopping and drained
+            while (!q.empty() && all.size() + q.front()->n_jobs <= MSM_MAX_JOBS) {
+                Req* r = q.front();
+                q.pop_front();
+                batch.push_back(r);
+                all.insert(all.end(), r->jobs, r->jobs + r->n_jobs);
+            }
+        }
+        auto serve = [&](const MsmJob* jobs, uint32_t n, Req* const* reqs, size_t n_reqs) {
+            int32_t status = SHP_OK;
+            std::string err;
+            try {
+                for (size_t i = 0; i < n_reqs; i++) SHP_HIP(hipStreamWaitEvent(st, reqs[i]->ready, 0));
+                msm_run_jobs(jobs, n, ws, st);
+                launches++;
+            } catch (const shp::Error& e) {
+                status = e.code;
+                err = e.what();
+            } catch (const std::exception& e) {
+                status = SHP_ERR_INTERNAL;
+                err = e.what();
+            }
+            for (size_t i = 0; i < n_reqs; i++) { reqs[i]->status = status; reqs[i]->err = err; }
+            return status;
+        };
+        if (serve(all.data(), (uint32_t)all.size(), batch.data(), batch.size()) != SHP_OK && batch.size() > 1)
+            for (Req* r : batch) serve(r->jobs, r->n_jobs, &r, 1);  // one bad request must not fail its neighbours
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (Req* r : batch) r->done = true;
+            requests += batch.size();
+        }
+        cv_done.notify_all();
+    }
+}
+
+shp::MsmCombiner* shp::msm_combiner_create(int device) {
+    std::unique_ptr<MsmCombiner> c(new MsmCombiner);
+    c->device = device;
+    SHP_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    c->ws.timers = &c->timers;
+    c->ws.min_waves = 256;                                         // throughput scheduling: long chains
+    MsmCombiner* raw = c.get();
+    c->th = std::thread([raw] { raw->loop(); });
+    return c.release();
+}
+
+void shp::msm_combiner_destroy(MsmCombiner* c) {
+    if (!c) return;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->stop = true;
+    }
+    c->cv_req.notify_all();
+    if (c->th.joinable()) c->th.join();
+    c->ws.release();
+    if (c->st) (void)hipStreamDestroy(c->st);
+    delete c;
+}
+
 static void msm_run_direct(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n_scalars, size_t stride,
                            uint32_t batch, G1Affine* h_out, hipStream_t st, shp_msm* m2 = nullptr,
                            const Fr* d_scalars2 = nullptr, size_t stride2 = 0, uint32_t batch2 = 0,

@@ -47,6 +47,7 @@ struct shp_pool {
     uint64_t next_ticket = 1;
     bool stopping = false;
     std::atomic<uint64_t> proofs_done{0};
+    shp::MsmCombiner* comb = nullptr;      // lanes > 4: one MSM launch serves every lane waiting at a commitment
 
     void worker(shp_prover* lane) {
         (void)hipSetDevice(device);
@@ -100,6 +101,17 @@ int32_t shp_pool_create(shp_pk* pk, uint32_t lanes, uint32_t queue_cap, shp_pool
             if (lanes > 4) (void)shp_prover_mode(pr, 1);   // many lanes: one host thread each, long MSM chains
             p->lanes.push_back(pr);
         }
+        static const bool combine = !(getenv("SHP_POOL_COMBINE") && getenv("SHP_POOL_COMBINE")[0] == '0');
+        if (lanes > 4 && combine) {
+            try {
+                p->comb = shp::msm_combiner_create(p->device);
+                for (size_t i = 0; i < p->lanes.size(); i++) shp_prover_attach_combiner(p->lanes[i], p->comb, i == 0);
+            } catch (...) {
+                for (auto* q : p->lanes) shp_prover_destroy(q);
+                shp::msm_combiner_destroy(p->comb);
+                throw;
+            }
+        }
         shp_pool* raw = p.get();
         for (auto* pr : p->lanes) p->workers.emplace_back([raw, pr] { raw->worker(pr); });
         *out = p.release();
@@ -116,6 +128,7 @@ int32_t shp_pool_destroy(shp_pool* p) {
         p->cv_work.notify_all();
         for (auto& t : p->workers) t.join();
         for (auto* pr : p->lanes) shp_prover_destroy(pr);
+        shp::msm_combiner_destroy(p->comb);
         delete p;
     });
 }

@@ -113,6 +113,12 @@ struct shp_pk {
 };
 
 static void launch_prog(hipStream_t st, const ProgArgs& a, uint32_t size) {
+    // up to 16 slots: the register-file interpreter (no LDS); SHP_PROG_REG=0 forces the LDS one (A/B, tests)
+    static const bool reg_ok = !(getenv("SHP_PROG_REG") && getenv("SHP_PROG_REG")[0] == '0');
+    if (reg_ok && a.nslots <= 16) {
+        hipLaunchKernelGGL(prog_fold_reg_kernel, dim3(size / PROG_THREADS), dim3(PROG_THREADS), 0, st, a);
+        return;
+    }
     size_t lds = (size_t)a.nslots * 8 * PROG_THREADS * 4;
     static std::once_flag attr_once;       // lanes launch from several host threads
     std::call_once(attr_once, [] {
@@ -535,6 +541,11 @@ struct shp_prover {
         owned.push_back(p);
         return (T*)p;
     }
+    // a pool's cross-lane MSM combiner (null: this lane launches its own commitments) and the event that hands
+    // the lane's stream position over to it
+    shp::MsmCombiner* comb = nullptr;
+    bool comb_profile_owner = false;
+    hipEvent_t comb_event = nullptr;
     // page-locked staging for every small host<->device copy of a proof (copies from pageable memory take the
     // runtime's slow path and serialise concurrent lanes); bump-allocated, rewound at the start of each proof
     PinnedBuf stage;
@@ -546,6 +557,7 @@ struct shp_prover {
         return (uint8_t*)stage.p + at;
     }
     ~shp_prover() {
+        if (comb_event) (void)hipEventDestroy(comb_event);
         stage.release();
         for (void* p : owned) (void)hipFree(p);
         msm_ws.release();
@@ -728,6 +740,22 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         memcpy(sbuf, src, bytes);
         SHP_HIP(hipMemcpyAsync(dst, sbuf, bytes, hipMemcpyHostToDevice, st));
     };
+    // commitments: `batch` columns over one basis (optionally a second job over another), through the pool's
+    // combiner when this lane has one; either way the lane's stream has drained when the points are back
+    auto commit = [&](shp_msm* m, const Fr* scalars, uint32_t batch, G1Affine* out, const MsmRows* rows = nullptr,
+                      shp_msm* m2 = nullptr, const Fr* scalars2 = nullptr, uint32_t batch2 = 0) {
+        if (batch + batch2 == 0) return;
+        if (pr->comb && m->direct && (!batch2 || m2->direct)) {
+            MsmJob jobs[2];
+            jobs[0] = MsmJob{m, scalars, n, batch, rows ? *rows : MsmRows{n, 0, 0}, out};
+            if (batch2) jobs[1] = MsmJob{m2, scalars2, n, batch2, MsmRows{n, 0, 0}, out + batch};
+            pr->comb->run(jobs, batch2 ? 2 : 1, st, pr->comb_event);
+        } else if (batch2) {
+            msm_run_ws2(m, scalars, n, batch, m2, scalars2, n, batch2, n, pr->msm_ws, out, st, rows);
+        } else {
+            msm_run_ws(m, pr->msm_ws, scalars, n, n, batch, out, st);
+        }
+    };
     // ---- P0/P1: witness, blinding rows, instance column
     std::vector<Fr> inputs(n_inputs);
     for (size_t i = 0; i < n_inputs; i++) {
@@ -769,7 +797,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     hipLaunchKernelGGL(chacha_fr_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->key, ctr_rand, n, pr->rand_poly);
     std::vector<G1Affine> pts(std::max<uint32_t>({A + 1, 2 * L, S + L + 1, P.degree}));
     const MsmRows adv_rows{P.adv_rows, u, n - u};     // assigned rows + blinding rows; the rest is zero
-    msm_run_ws2(srs->msm_gl, V(0), n, A, srs->msm_g, pr->rand_poly, n, 1, n, pr->msm_ws, pts.data(), st, &adv_rows);
+    commit(srs->msm_gl, V(0), A, pts.data(), &adv_rows, srs->msm_g, pr->rand_poly, 1);
     const G1Affine rand_comm = pts[A];
     for (uint32_t c = 0; c < A; c++) tr.write_point(pts[c].x, pts[c].y);
     const Fr theta = tr.squeeze();
@@ -832,7 +860,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
                            V(I_PIN), V(I_PIN + 1), (size_t)2 * n, pr->rep_scratch, pr->rank, pr->blinds, pr->err);
         uint32_t* herr = (uint32_t*)pr->stage_alloc(4);  // read back with the commitments (the MSM run synchronises)
         SHP_HIP(hipMemcpyAsync(herr, pr->err, 4, hipMemcpyDeviceToHost, st));
-        msm_run_ws(srs->msm_gl, pr->msm_ws, V(I_PIN), n, n, 2 * L, pts.data(), st);
+        commit(srs->msm_gl, V(I_PIN), 2 * L, pts.data());
         SHP_REQUIRE(*herr == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
         for (uint32_t i = 0; i < 2 * L; i++) tr.write_point(pts[i].x, pts[i].y);
     }
@@ -869,7 +897,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     SHP_REQUIRE(ctr == ctr_rand, SHP_ERR_INTERNAL, "prove: blinding stream position of the random polynomial");
     ctr += n;
     ctr += 1;
-    if (S + L) msm_run_ws(srs->msm_gl, pr->msm_ws, V(I_PZ), n, n, S + L, pts.data(), st);
+    commit(srs->msm_gl, V(I_PZ), S + L, pts.data());
     for (uint32_t i = 0; i < S + L; i++) tr.write_point(pts[i].x, pts[i].y);
     tr.write_point(rand_comm.x, rand_comm.y);
     pc.mark("products_msm");
@@ -927,7 +955,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     ntt_launch(ctx, pr->h, pr->h, ek, 1, back, st, pr->ntt_tmp);
     const uint32_t npieces = P.degree - 1;
     ctr += npieces;                                      // one (unused) blind per quotient piece
-    msm_run_ws(srs->msm_g, pr->msm_ws, pr->h, n, n, npieces, pts.data(), st);
+    commit(srs->msm_g, pr->h, npieces, pts.data());
     for (uint32_t i = 0; i < npieces; i++) tr.write_point(pts[i].x, pts[i].y);
     pc.mark("quotient_msm");
     // ---- P11: evaluations
@@ -1051,7 +1079,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
                        pr->points, n, pr->pdiff);
     batch_invert(pr->pdiff, pr->dinv, (uint32_t)points.size());
     hipLaunchKernelGGL(shplonk_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals);
-    msm_run_ws(srs->msm_gl, pr->msm_ws, pr->wvals, n, n, 1, pts.data(), st);
+    commit(srs->msm_gl, pr->wvals, 1, pts.data());
     tr.write_point(pts[0].x, pts[0].y);
     pc.mark("W");
     // ---- P13: W'
@@ -1083,7 +1111,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     hipLaunchKernelGGL(point_diff_kernel, dim3(ceil_div(n, 256), 1), dim3(256), 0, st, pk->omegas, pr->points, n, pr->mdiff);
     batch_invert(pr->mdiff, pr->mdiff + n, 1);
     hipLaunchKernelGGL(shplonk_wp_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals + n);
-    msm_run_ws(srs->msm_gl, pr->msm_ws, pr->wvals + n, n, n, 1, pts.data(), st);
+    commit(srs->msm_gl, pr->wvals + n, 1, pts.data());
     tr.write_point(pts[0].x, pts[0].y);
     pc.mark("Wprime");
     SHP_HIP(hipGetLastError());
@@ -1261,6 +1289,10 @@ int32_t shp_prover_profile(shp_prover* p, int32_t enable) {
         SHP_REQUIRE(p, SHP_ERR_INVALID_ARG, "prover_profile: null prover");
         p->timers.enabled = enable != 0;
         p->timers.reset();
+        if (p->comb && p->comb_profile_owner) {              // idle pool assumed (bench toggles between steps)
+            p->comb->timers.enabled = enable != 0;
+            p->comb->timers.reset();
+        }
     });
 }
 
@@ -1268,10 +1300,22 @@ int32_t shp_prover_profile_read(shp_prover* p, uint32_t index, const char** name
     return guarded([&] {
         SHP_REQUIRE(p && index < KID_COUNT, SHP_ERR_INVALID_ARG, "prover_profile_read: bad argument");
         if (name) *name = KERNEL_NAMES[index];
-        if (launches) *launches = p->timers.launches[index];
-        if (total_ms) *total_ms = p->timers.total_ms[index];
+        const bool with_comb = p->comb && p->comb_profile_owner;
+        if (launches) *launches = p->timers.launches[index] + (with_comb ? p->comb->timers.launches[index] : 0);
+        if (total_ms) *total_ms = p->timers.total_ms[index] + (with_comb ? p->comb->timers.total_ms[index] : 0.0);
     });
 }
+
+}  // extern "C"
+
+void shp_prover_attach_combiner(shp_prover* p, shp::MsmCombiner* c, bool profile_owner) {
+    if (!p) return;
+    p->comb = c;
+    p->comb_profile_owner = c && profile_owner;
+    if (c && !p->comb_event) SHP_HIP(hipEventCreateWithFlags(&p->comb_event, hipEventDisableTiming));
+}
+
+extern "C" {
 
 int32_t shp_prover_destroy(shp_prover* p) {
     return guarded([&] { delete p; });

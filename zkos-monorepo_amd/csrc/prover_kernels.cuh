@@ -98,6 +98,70 @@ __global__ __launch_bounds__(PROG_THREADS) void prog_fold_kernel(ProgArgs a) {
     st(a.out + row, acc);
 }
 
+// The same program with the slot file in VECTOR REGISTERS (plans with <= 16 slots): one 16-wide register vector
+// per limb, indexed by the wave-uniform slot number (gfx9 VGPR index mode / v_movrel) -- no LDS at all, so the
+// launch is not held to five waves per CU by 30 KB of slots per wave and leaves the CU's LDS to the kernels of
+// the other proving lanes.
+typedef uint32_t slotvec_t __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(PROG_THREADS) void prog_fold_reg_kernel(ProgArgs a) {
+    slotvec_t L[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) L[k] = (slotvec_t)(0u);
+    const uint32_t row = blockIdx.x * PROG_THREADS + threadIdx.x;
+    auto get = [&](uint32_t s) {
+        s = __builtin_amdgcn_readfirstlane(s);
+        Fr v;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v.l[k] = L[k][s];
+        return v;
+    };
+    auto put = [&](uint32_t s, const Fr& v) {
+        s = __builtin_amdgcn_readfirstlane(s);
+#pragma unroll
+        for (int k = 0; k < 8; k++) L[k][s] = v.l[k];
+    };
+    Fr acc = a.acc_in ? ld(a.acc_in + row) : Fr::zero();
+    // one read site and one write site of the slot vectors per instruction (operands are fetched whether or not
+    // the opcode uses them): the register allocator keeps the eight vectors in place instead of copying them
+    // at every merge of a per-opcode branch
+    for (uint32_t i = 0; i < a.n_instr; i++) {
+        const Instr in = a.prog[i];
+        const Fr x = get(in.a & 15u), y = get(in.b & 15u);
+        Fr r = x;
+        uint32_t dst = in.dst;
+        switch (in.op) {
+            case OP_CONST: r = ld(a.consts + in.a); break;
+            case OP_ADV: {
+                Query q = a.adv_q[in.a];
+                uint32_t rr = (row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask;
+                r = ld(a.adv_base + (size_t)q.col * a.adv_stride + rr);
+                break;
+            }
+            case OP_FIX: {
+                Query q = a.fix_q[in.a];
+                uint32_t rr = (row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask;
+                r = ld(a.fix_base + (size_t)q.col * a.fix_stride + rr);
+                break;
+            }
+            case OP_INST: {
+                Query q = a.inst_q[in.a];
+                uint32_t rr = (row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask;
+                r = ld(a.inst_base + rr);
+                break;
+            }
+            case OP_ADD: r = x + y; break;
+            case OP_SUB: r = x - y; break;
+            case OP_MUL: r = x * y; break;
+            case OP_NEG: r = Fr::neg(x); break;
+            case OP_OUT: acc = acc * a.mult + x; dst = in.a; break;      // the slot keeps its value
+            default: dst = in.a; break;
+        }
+        put(dst & 15u, r);
+    }
+    st(a.out + row, acc);
+}
+
 // ------------------------------------------------------------------ blinding stream
 __global__ void chacha_fr_kernel(const uint32_t* key8, uint64_t counter0, uint32_t count, Fr* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
