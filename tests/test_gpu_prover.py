@@ -302,6 +302,27 @@ def test_witness_schedule_threads_give_identical_proofs(shp, oracle, gpu_ctx, sm
     pr.close(); pk.close(); params.close()
 
 
+def test_pool_with_msm_combiner_same_bytes(shp, oracle, gpu_ctx, monkeypatch):
+    """SHP_POOL_COMBINE=1: the commitments of all lanes waiting at an MSM phase are served by one multi-job launch
+    (msm_run_jobs through MsmCombiner); proofs stay byte-identical to a lone lane and to the oracle"""
+    PL, C, plan, lay, osrs, opk, params, pk = setup(shp, oracle, gpu_ctx, True)
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    rnd = random.Random(99)
+    count = 24
+    wits = [C.withdraw_witness_inputs(lay, H, rnd, 2**31 + i, 2**20 + i) for i in range(count)]
+    blobs = [b"".join(int(x).to_bytes(32, "little") for x in w) for w in wits]
+    seeds = [bytes([i + 7]) * 32 for i in range(count)]
+    monkeypatch.setenv("SHP_POOL_COMBINE", "1")
+    pool = shp.Pool(pk, 6)
+    monkeypatch.delenv("SHP_POOL_COMBINE")
+    got = pool.prove_batch(b"".join(blobs), b"".join(seeds), count)
+    single = shp.Prover(pk)
+    for i in range(count):
+        assert got[i] == single.prove_bytes(blobs[i], seeds[i]), f"combined-MSM proof {i} differs"
+    assert got[5] == PL.prove(opk, osrs, wits[5], seeds[5])
+    pool.close(); single.close(); pk.close(); params.close()
+
+
 def test_pool_queue_bound_and_argument_errors(shp, oracle, gpu_ctx):
     """bounded queue (the reference's task pool answers 504 when it is full): SHP_ERR_BUSY, then the pool drains;
     wrong witness length -> SHP_ERR_INVALID_ARG"""

@@ -101,8 +101,10 @@ int32_t shp_pool_create(shp_pk* pk, uint32_t lanes, uint32_t queue_cap, shp_pool
             if (lanes > 4) (void)shp_prover_mode(pr, 1);   // many lanes: one host thread each, long MSM chains
             p->lanes.push_back(pr);
         }
-        static const bool combine = !(getenv("SHP_POOL_COMBINE") && getenv("SHP_POOL_COMBINE")[0] == '0');
-        if (lanes > 4 && combine) {
+        // opt-in (SHP_POOL_COMBINE=1): on one MI355X the pool is not limited by the size of its MSM launches --
+        // 16 lanes lose 19 % behind the combiner's serial launches, 48 lanes only draw level
+        const char* ce = getenv("SHP_POOL_COMBINE");
+        if (lanes > 1 && ce && ce[0] == '1') {
             try {
                 p->comb = shp::msm_combiner_create(p->device);
                 for (size_t i = 0; i < p->lanes.size(); i++) shp_prover_attach_combiner(p->lanes[i], p->comb, i == 0);
