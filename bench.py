@@ -206,8 +206,12 @@ def main():
             pv = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_valu_prove.json")))
             wi = pv["valu_wave_instructions_per_proof"]
             ideal_s = wi * 4.0 / (1024 * 2.4e9)
+            # 4 cycles is the architectural issue slot; the best rate measured on this chip for the instructions a
+            # Montgomery product is made of is 5.2 cycles (4+ waves per SIMD; 8.0 for a lone wave:
+            # profiles/r01_instr_rate_gfx950.log), so the second fraction is the one a kernel can actually approach
+            rate = total_proofs / elapsed / n_gpus
             valu = {"wave_instructions_per_proof": wi, "ideal_us_per_proof": 1e6 * ideal_s,
-                    "issue_frac": ideal_s * (total_proofs / elapsed / n_gpus)}
+                    "issue_frac": ideal_s * rate, "issue_frac_of_measured_peak": ideal_s * (5.2 / 4.0) * rate}
         except (OSError, KeyError):
             pass
         out = {
