@@ -888,7 +888,7 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
         parts += (uint64_t)jobs[k].batch * segs[k].gx * gy;
     }
     ws.pf.reserve(parts * sizeof(G1X));
-    ws.out.reserve(total * sizeof(G1X));
+    ws.h_out.reserve(total * sizeof(G1X));                     // before the launch: the final sums are written
     ws.segs.reserve(n_jobs * sizeof(DirectSeg));
     ws.h_segs.reserve(n_jobs * sizeof(DirectSeg));
     memcpy(ws.h_segs.p, segs.data(), n_jobs * sizeof(DirectSeg));
@@ -903,11 +903,9 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
     tm->end(st);
     tm->begin(KID_MSM_DIRECT_FINAL, st);
     hipLaunchKernelGGL(msm_direct_final_kernel, dim3((uint32_t)total), dim3(MSM_THREADS), 0, st, a.segs, n_jobs, gy,
-                       ws.pf.as<G1X>(), ws.out.as<G1X>());
+                       ws.pf.as<G1X>(), ws.h_out.as<G1X>());   // straight into pinned host memory: no copy dispatch
     tm->end(st);
     SHP_HIP(hipGetLastError());
-    ws.h_out.reserve(total * sizeof(G1X));
-    SHP_HIP(hipMemcpyAsync(ws.h_out.p, ws.out.p, total * sizeof(G1X), hipMemcpyDeviceToHost, st));
     SHP_HIP(hipStreamSynchronize(st));
     tm->collect();
     ws.h_aff.resize(total);

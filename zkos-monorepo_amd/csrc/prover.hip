@@ -1013,14 +1013,14 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     add_job({7, 0}, 0);
     SHP_REQUIRE(jobs.size() <= 512, SHP_ERR_INVALID_ARG, "prove: too many evaluations");
     h2d(pr->jobs, jobs.data(), jobs.size() * sizeof(EvalJob));
-    hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)jobs.size()), dim3(256), 0, st, pr->jobs, pr->pw, n, pr->evals);
+    // the evaluations land in the pinned arena directly (one store per job over PCIe, no copy dispatch)
+    Fr* const evals = (Fr*)pr->stage_alloc(jobs.size() * sizeof(Fr));
+    hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)jobs.size()), dim3(256), 0, st, pr->jobs, pr->pw, n, evals);
     // Lagrange values of hx and the random polynomial for the evaluation-form opening
     SHP_HIP(hipMemcpyAsync(pr->lag2, pr->hx, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     SHP_HIP(hipMemcpyAsync(pr->lag2 + n, pr->rand_poly, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     NttOpts fwd;
     ntt_launch(ctx, pr->lag2, pr->lag2, k, 2, fwd, st, pr->ntt_tmp);
-    const Fr* evals = (const Fr*)pr->stage_alloc(jobs.size() * sizeof(Fr));
-    SHP_HIP(hipMemcpyAsync((void*)evals, pr->evals, jobs.size() * sizeof(Fr), hipMemcpyDeviceToHost, st));
     SHP_HIP(hipStreamSynchronize(st));
     std::map<std::pair<PolyKey, int32_t>, Fr> ev;
     for (size_t i = 0; i < jobs.size(); i++) ev[job_key[i]] = evals[i];
