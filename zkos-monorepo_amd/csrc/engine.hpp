@@ -69,14 +69,15 @@ struct MsmWorkspace {
     KernelTimers* timers = nullptr;
     DevBuf cnt, start, entries, pf, pl, buckets, out, wg_hist;
     PinnedBuf h_out, h_totals;             // G1X sums / per-MSM entry counts, read back after each run
-    DevBuf segs;                           // direct mode: the launch's segment table
+    DevBuf segs;                           // direct mode: segment tables (16 cached slots of 4 + scratch)
     PinnedBuf h_segs;
+    uint32_t seg_cached = 0, seg_cache_n[16] = {0};
     std::vector<G1Affine> h_aff;
     uint64_t last_adds = 0, last_bytes = 0;
     uint64_t min_waves = 0;     // direct mode: waves a launch should have before chains get longer (0 = default)
     void release() {
         cnt.release(); start.release(); entries.release(); pf.release(); pl.release(); buckets.release(); out.release();
-        wg_hist.release(); h_out.release(); h_totals.release(); segs.release(); h_segs.release();
+        wg_hist.release(); h_out.release(); h_totals.release(); segs.release(); h_segs.release(); seg_cached = 0;
     }
 };
 

@@ -889,12 +889,33 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
     }
     ws.pf.reserve(parts * sizeof(G1X));
     ws.h_out.reserve(total * sizeof(G1X));                     // before the launch: the final sums are written
-    ws.segs.reserve(n_jobs * sizeof(DirectSeg));
-    ws.h_segs.reserve(n_jobs * sizeof(DirectSeg));
-    memcpy(ws.h_segs.p, segs.data(), n_jobs * sizeof(DirectSeg));
-    SHP_HIP(hipMemcpyAsync(ws.segs.p, ws.h_segs.p, n_jobs * sizeof(DirectSeg), hipMemcpyHostToDevice, st));
+    // segment tables live in a small device arena: a prover's six commitment phases present the same tables
+    // proof after proof (same buffers, same shapes), so short tables are uploaded once and found again by
+    // content; longer or novel ones (a combiner's mixes) go through the scratch region behind the cache slots
+    constexpr uint32_t SLOT_SEGS = 4, SLOTS = 16, SCRATCH_AT = SLOT_SEGS * SLOTS;
+    ws.segs.reserve((SCRATCH_AT + shp::MSM_MAX_JOBS) * sizeof(DirectSeg));
+    ws.h_segs.reserve((SCRATCH_AT + shp::MSM_MAX_JOBS) * sizeof(DirectSeg));
+    const size_t seg_bytes = n_jobs * sizeof(DirectSeg);
+    uint32_t seg_at = SCRATCH_AT;
+    bool upload = true;
+    if (n_jobs <= SLOT_SEGS) {
+        for (uint32_t e = 0; e < ws.seg_cached && upload; e++)
+            if (ws.seg_cache_n[e] == n_jobs && memcmp(ws.h_segs.as<DirectSeg>() + e * SLOT_SEGS, segs.data(), seg_bytes) == 0) {
+                seg_at = e * SLOT_SEGS;
+                upload = false;
+            }
+        if (upload && ws.seg_cached < SLOTS) {
+            seg_at = ws.seg_cached * SLOT_SEGS;
+            ws.seg_cache_n[ws.seg_cached++] = n_jobs;
+        }
+    }
+    if (upload) {
+        memcpy(ws.h_segs.as<DirectSeg>() + seg_at, segs.data(), seg_bytes);
+        SHP_HIP(hipMemcpyAsync(ws.segs.as<DirectSeg>() + seg_at, ws.h_segs.as<DirectSeg>() + seg_at, seg_bytes,
+                               hipMemcpyHostToDevice, st));
+    }
     DirectArgs a;
-    a.segs = ws.segs.as<DirectSeg>(); a.n_segs = n_jobs;
+    a.segs = ws.segs.as<DirectSeg>() + seg_at; a.n_segs = n_jobs;
     a.n_table = m0->n;
     a.c = m0->c; a.W = W; a.NB = m0->NB; a.T = T; a.bias = m0->bias; a.partials = ws.pf.as<G1X>();
     KernelTimers none, *tm = ws.timers ? ws.timers : &none;

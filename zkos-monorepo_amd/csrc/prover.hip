@@ -112,10 +112,13 @@ struct shp_pk {
     }
 };
 
-static void launch_prog(hipStream_t st, const ProgArgs& a, uint32_t size) {
-    // up to 16 slots: the register-file interpreter (no LDS); SHP_PROG_REG=0 forces the LDS one (A/B, tests)
-    static const bool reg_ok = !(getenv("SHP_PROG_REG") && getenv("SHP_PROG_REG")[0] == '0');
-    if (reg_ok && a.nslots <= 16) {
+static void launch_prog(hipStream_t st, const ProgArgs& a, uint32_t size, bool throughput) {
+    // up to 16 slots: the register-file interpreter (no LDS) for throughput lanes -- it leaves the CU's LDS to the
+    // other lanes' kernels (+3 % pool throughput); a lone proof is 17 us faster with the LDS one (231 vs 214 us).
+    // SHP_PROG_REG=0 / 1 forces one of them (A/B, tests)
+    static const char* const force = getenv("SHP_PROG_REG");
+    const bool use_reg = force ? force[0] != '0' : throughput;
+    if (use_reg && a.nslots <= 16) {
         hipLaunchKernelGGL(prog_fold_reg_kernel, dim3(size / PROG_THREADS), dim3(PROG_THREADS), 0, st, a);
         return;
     }
@@ -543,6 +546,7 @@ struct shp_prover {
     }
     // a pool's cross-lane MSM combiner (null: this lane launches its own commitments) and the event that hands
     // the lane's stream position over to it
+    bool throughput = false;               // shp_prover_mode(1): scheduling choices of a pool lane
     shp::MsmCombiner* comb = nullptr;
     bool comb_profile_owner = false;
     hipEvent_t comb_event = nullptr;
@@ -827,10 +831,10 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
             pa.mult = theta; pa.acc_in = nullptr;
             pa.prog = pk->lk_in_prog[l]; pa.n_instr = (uint32_t)lk.in_prog.size(); pa.nslots = lk.in_slots;
             pa.out = pr->cin + (size_t)l * n;
-            launch_prog(st, pa, n);
+            launch_prog(st, pa, n, pr->throughput);
             pa.prog = pk->lk_tab_prog[l]; pa.n_instr = (uint32_t)lk.tab_prog.size(); pa.nslots = lk.tab_slots;
             pa.out = pr->ctab + (size_t)l * n;
-            launch_prog(st, pa, n);
+            launch_prog(st, pa, n, pr->throughput);
             hipLaunchKernelGGL(to_raw_kernel, dim3(ceil_div(u, 256)), dim3(256), 0, st, pr->cin + (size_t)l * n,
                                pr->sort_raw + (size_t)(2 * l) * n, u);
             hipLaunchKernelGGL(to_raw_kernel, dim3(ceil_div(u, 256)), dim3(256), 0, st, pr->ctab + (size_t)l * n,
@@ -917,7 +921,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     pa.prog = pk->gate_prog; pa.n_instr = (uint32_t)P.gate_prog.size(); pa.nslots = P.gate_slots;
     pa.out = pr->h;
     pr->timers.begin(KID_PROG, st);
-    launch_prog(st, pa, ne);
+    launch_prog(st, pa, ne, pr->throughput);
     pr->timers.end(st);
     if (S) {
         PermQArgs q;
@@ -938,10 +942,10 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         pa.mult = theta; pa.acc_in = nullptr;
         pa.prog = pk->lk_in_prog[l]; pa.n_instr = (uint32_t)lk.in_prog.size(); pa.nslots = lk.in_slots;
         pa.out = pr->aux_ext;
-        launch_prog(st, pa, ne);
+        launch_prog(st, pa, ne, pr->throughput);
         pa.prog = pk->lk_tab_prog[l]; pa.n_instr = (uint32_t)lk.tab_prog.size(); pa.nslots = lk.tab_slots;
         pa.out = pr->aux_ext + ne;
-        launch_prog(st, pa, ne);
+        launch_prog(st, pa, ne, pr->throughput);
         LookupQArgs q;
         q.z = CS(I_LZ + l); q.pin = CS(I_PIN + 2 * l); q.ptab = CS(I_PIN + 2 * l + 1);
         q.ain = pr->aux_ext; q.stab = pr->aux_ext + ne;
@@ -1280,6 +1284,7 @@ int32_t shp_prover_mode(shp_prover* p, uint32_t mode) {
     return guarded([&] {
         SHP_REQUIRE(p && mode <= 1, SHP_ERR_INVALID_ARG, "prover_mode: null prover or unknown mode");
         p->msm_ws.min_waves = mode ? 256 : 0;
+        p->throughput = mode != 0;
         if (mode) set_witness_threads(p, 1);
     });
 }
