@@ -521,7 +521,7 @@ struct shp_prover {
     uint32_t *rep_scratch = nullptr, *err = nullptr;
     Fr *rand_poly = nullptr, *h = nullptr, *aux_ext = nullptr; // h [ne], aux_ext [2][ne]
     Fr *hx = nullptr, *lag2 = nullptr;                         // hx coeffs; [2][n] Lagrange values of hx, rand
-    Fr *pw = nullptr, *points = nullptr, *evals = nullptr;
+    Fr *pw = nullptr, *points = nullptr;
     EvalJob* jobs = nullptr;
     Fr *fsets = nullptr, *pdiff = nullptr, *dinv = nullptr, *wvals = nullptr, *mdiff = nullptr;
     LincombArgs* lin = nullptr;
@@ -607,7 +607,6 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->lag2 = pr->dalloc<Fr>((size_t)2 * n);
     pr->pw = pr->dalloc<Fr>((size_t)MAX_POINTS * n);
     pr->points = pr->dalloc<Fr>(MAX_POINTS);
-    pr->evals = pr->dalloc<Fr>(512);
     pr->jobs = pr->dalloc<EvalJob>(512);
     pr->fsets = pr->dalloc<Fr>((size_t)MAX_SETS * n);
     pr->pdiff = pr->dalloc<Fr>((size_t)MAX_POINTS * n);
