@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--lanes", type=int, default=16, help="concurrent proving lanes (streams) per GPU")
     ap.add_argument("--proofs-per-lane", type=int, default=4, help="proofs each lane produces back to back in one step")
-    ap.add_argument("--latency-proofs", type=int, default=20)
+    ap.add_argument("--latency-proofs", type=int, default=100, help="single-lane proofs timed for p50 (SURVEY 8d config 2: 100 runs)")
     ap.add_argument("--cpu-proofs", type=int, default=3, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)   # gloo path test, no GPU
     a = ap.parse_args()

@@ -600,10 +600,10 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->sort_out = pr->dalloc<Fr>((size_t)2 * L * n);
     pr->rep_scratch = pr->dalloc<uint32_t>((size_t)L * n);
     pr->err = pr->dalloc<uint32_t>(4);
-    pr->rand_poly = pr->dalloc<Fr>(n);
     pr->h = pr->dalloc<Fr>(ne);
     pr->aux_ext = pr->dalloc<Fr>((size_t)2 * ne);
-    pr->hx = pr->dalloc<Fr>(n);
+    pr->hx = pr->dalloc<Fr>((size_t)2 * n);          // h(X) folded at x, then the random polynomial: one NTT batch
+    pr->rand_poly = pr->hx + n;
     pr->lag2 = pr->dalloc<Fr>((size_t)2 * n);
     pr->pw = pr->dalloc<Fr>((size_t)MAX_POINTS * n);
     pr->points = pr->dalloc<Fr>(MAX_POINTS);
@@ -1020,10 +1020,8 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     Fr* const evals = (Fr*)pr->stage_alloc(jobs.size() * sizeof(Fr));
     hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)jobs.size()), dim3(256), 0, st, pr->jobs, pr->pw, n, evals);
     // Lagrange values of hx and the random polynomial for the evaluation-form opening
-    SHP_HIP(hipMemcpyAsync(pr->lag2, pr->hx, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    SHP_HIP(hipMemcpyAsync(pr->lag2 + n, pr->rand_poly, (size_t)n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     NttOpts fwd;
-    ntt_launch(ctx, pr->lag2, pr->lag2, k, 2, fwd, st, pr->ntt_tmp);
+    ntt_launch(ctx, pr->hx, pr->lag2, k, 2, fwd, st, pr->ntt_tmp);   // out of place: hx | rand_poly are adjacent
     SHP_HIP(hipStreamSynchronize(st));
     std::map<std::pair<PolyKey, int32_t>, Fr> ev;
     for (size_t i = 0; i < jobs.size(); i++) ev[job_key[i]] = evals[i];
