@@ -48,6 +48,10 @@ struct NttOpts {
     size_t in_stride = 0;     // elements between input polys (0 = in_len or 2^log_n)
     int pre_pattern = 0;      // 1: input i scaled by [1, zeta, zeta^2][i % 3]
     int post_pattern = 0;     // 1: output i scaled by [1, zeta^2, zeta][i % 3]
+    // coset evaluation: `twist_count` transforms per input polynomial, transform b reads polynomial b / twist_count
+    // with coefficient i scaled by twist[(b % twist_count) * 2^log_n + i] (= c_j^i: values on the coset c_j * H)
+    const Fr* twist = nullptr;
+    uint32_t twist_count = 0;
 };
 // `tmp`: caller-owned ping-pong buffer of batch * 2^log_n elements (needed when log_n > 11);
 // nullptr = the context's shared buffer (single-stream use only)

@@ -38,6 +38,8 @@ struct PassParams {
     const Fr* tw_lo;
     const Fr* tw_hi;
     Fr scale, zeta, zeta2;
+    const Fr* twist;          // first pass only (null: none)
+    uint32_t src_div;         // first pass: transforms per input polynomial (>= 1)
 };
 
 __device__ __forceinline__ Fr lds_load(const uint4* lo, const uint4* hi, uint32_t i) {
@@ -74,7 +76,9 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
     __shared__ uint4 sh_hi[1 << NTT_TILE_LOG];
     const uint32_t tid = threadIdx.x;
     const uint32_t tile = blockIdx.x;
-    const Fr* src = p.src + (size_t)blockIdx.y * p.src_stride;
+    const uint32_t poly = p.is_first && p.src_div > 1 ? blockIdx.y / p.src_div : blockIdx.y;
+    const Fr* src = p.src + (size_t)poly * p.src_stride;
+    const Fr* twist = p.is_first && p.twist ? p.twist + ((size_t)(blockIdx.y - poly * p.src_div) << p.log_n) : nullptr;
     Fr* dst = p.dst + (size_t)blockIdx.y * p.dst_stride;
     const uint32_t s = p.s, c = p.c;
     const uint32_t L = 1u << s, V = 1u << c, E = L << c;
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
                 if (m == 1) val = val * p.zeta;
                 else if (m == 2) val = val * p.zeta2;
             }
+            if (twist) val = val * gload(twist + gi);
         }
         lds_store(sh_lo, sh_hi, li, val);
     }
@@ -304,6 +309,8 @@ void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_
         p.scale = T.n_inv;
         p.zeta = ctx->zeta;
         p.zeta2 = ctx->zeta2;
+        p.twist = o.twist;
+        p.src_div = o.twist && o.twist_count ? o.twist_count : 1;
         p.small_tw = ctx->ntt_small[dir];
         p.tw_lo = T.lo[dir];
         p.tw_hi = T.hi[dir];

@@ -76,6 +76,14 @@ struct shp_pk {
     shp_srs* srs = nullptr;
     PlanData plan;
     uint32_t n = 0, ne = 0, NV = 0;               // NV = committed Lagrange polys per proof
+    // The quotient domain: the quotient has degree < (d - 1) n, so nc = d - 1 cosets c_j * H of size n carry it,
+    // c_j = zeta * omega_ext^j -- a subset of halo2's extended domain zeta * H_ext (2^e n points), laid out
+    // coset-major: index j * n + t <-> point c_j * omega^t.  nq = nc * n (7 n instead of 8 n for the withdraw
+    // circuit).  twist[j][i] = c_j^i turns coefficients into values on coset j with one size-n NTT; cinv[j][t] =
+    // c_j^-t and the inverse Vandermonde matrix on the nodes c_j^n turn the per-coset interpolants back into the
+    // quotient pieces (coset_combine_kernel).
+    uint32_t nc = 0, nq = 0;
+    Fr *twist = nullptr, *cinv = nullptr, *vinv = nullptr;
     // device-resident constants
     Fr *fixed_vals = nullptr, *fixed_polys = nullptr, *fixed_cos = nullptr;
     Fr *sigma_vals = nullptr, *sigma_polys = nullptr, *sigma_cos = nullptr;
@@ -156,16 +164,33 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     pk->delta = fr_delta();
     pk->zeta = fr_zeta();
     Fr om_ext = fr_root_of_unity(ek);
-    // omega^i and zeta * omega_ext^i
-    std::vector<Fr> om(n), xe(ne);
+    const uint32_t nc = P.degree - 1, nq = nc * n;
+    SHP_REQUIRE(nc >= 1 && nc <= MAX_COSETS && nc <= (1u << (ek - k)), SHP_ERR_INVALID_ARG, "keygen: unsupported constraint degree");
+    pk->nc = nc;
+    pk->nq = nq;
+    // omega^i; the quotient domain's points c_j omega^t, twists c_j^i and untwists c_j^-t
+    std::vector<Fr> om(n), xe(nq), tw(nq), ci(nq), cj(nc);
     {
         Fr a = Fr::one();
         for (uint32_t i = 0; i < n; i++) { om[i] = a; a = a * pk->omega; }
         a = pk->zeta;
-        for (uint32_t i = 0; i < ne; i++) { xe[i] = a; a = a * om_ext; }
+        for (uint32_t j = 0; j < nc; j++) { cj[j] = a; a = a * om_ext; }
+        for (uint32_t j = 0; j < nc; j++) {
+            const Fr cinv1 = Fr::inv(cj[j]);
+            Fr p = Fr::one(), q = Fr::one();
+            for (uint32_t t = 0; t < n; t++) {
+                xe[(size_t)j * n + t] = cj[j] * om[t];
+                tw[(size_t)j * n + t] = p;
+                ci[(size_t)j * n + t] = q;
+                p = p * cj[j];
+                q = q * cinv1;
+            }
+        }
     }
     pk->omegas = pk->dupload(om);
     pk->x_ext = pk->dupload(xe);
+    pk->twist = pk->dupload(tw);
+    pk->cinv = pk->dupload(ci);
     pk->delta_pow.resize(PC);
     {
         Fr a = Fr::one();
@@ -185,40 +210,69 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     pk->sigma_vals = pk->dupload(sv);
     pk->fixed_polys = pk->dalloc<Fr>((size_t)F * n);
     pk->sigma_polys = pk->dalloc<Fr>((size_t)PC * n);
-    pk->fixed_cos = pk->dalloc<Fr>((size_t)F * ne);
-    pk->sigma_cos = pk->dalloc<Fr>((size_t)PC * ne);
-    Fr* tmp = pk->dalloc<Fr>((size_t)std::max(F, PC) * ne);
+    pk->fixed_cos = pk->dalloc<Fr>((size_t)F * nq);
+    pk->sigma_cos = pk->dalloc<Fr>((size_t)PC * nq);
+    Fr* tmp = pk->dalloc<Fr>((size_t)std::max<uint32_t>({F, PC, 3}) * nq);
     NttOpts inv;
     inv.inverse = true;
-    NttOpts ext;
-    ext.in_len = n;
-    ext.in_stride = n;
-    ext.pre_pattern = 1;
+    NttOpts ext;                                   // coefficients -> values on the nc cosets, [poly][coset][n]
+    ext.twist = pk->twist;
+    ext.twist_count = nc;
     ntt_launch(ctx, pk->fixed_vals, pk->fixed_polys, k, F, inv, st, tmp);
-    ntt_launch(ctx, pk->fixed_polys, pk->fixed_cos, ek, F, ext, st, tmp);
+    ntt_launch(ctx, pk->fixed_polys, pk->fixed_cos, k, F * nc, ext, st, tmp);
     ntt_launch(ctx, pk->sigma_vals, pk->sigma_polys, k, PC, inv, st, tmp);
-    ntt_launch(ctx, pk->sigma_polys, pk->sigma_cos, ek, PC, ext, st, tmp);
-    // l_0, l_last, l_active on the extended coset
+    ntt_launch(ctx, pk->sigma_polys, pk->sigma_cos, k, PC * nc, ext, st, tmp);
+    // l_0, l_last, l_active on the quotient domain
     std::vector<Fr> lv((size_t)3 * n, Fr::zero());
     lv[0] = Fr::one();
     lv[(size_t)n + P.usable] = Fr::one();
     for (uint32_t r = 0; r < P.usable; r++) lv[(size_t)2 * n + r] = Fr::one();
     Fr* d_lv = pk->dupload(lv);
     Fr* d_lp = pk->dalloc<Fr>((size_t)3 * n);
-    Fr* d_lc = pk->dalloc<Fr>((size_t)3 * ne);
+    Fr* d_lc = pk->dalloc<Fr>((size_t)3 * nq);
     ntt_launch(ctx, d_lv, d_lp, k, 3, inv, st, tmp);
-    ntt_launch(ctx, d_lp, d_lc, ek, 3, ext, st, tmp);
+    ntt_launch(ctx, d_lp, d_lc, k, 3 * nc, ext, st, tmp);
     pk->l0 = d_lc;
-    pk->l_last = d_lc + ne;
-    pk->l_active = d_lc + 2 * (size_t)ne;
-    // 1 / ((zeta omega_ext^i)^n - 1), period 2^(ek-k)
+    pk->l_last = d_lc + nq;
+    pk->l_active = d_lc + 2 * (size_t)nq;
+    // per coset: 1 / (c_j^n - 1); and the inverse of the Vandermonde matrix V[j][m] = (c_j^n)^m (Gauss-Jordan)
     {
-        uint32_t per = 1u << (ek - k);
-        Fr zn = Fr::pow_u64(pk->zeta, n), wn = Fr::pow_u64(om_ext, n);
-        std::vector<Fr> ti(per);
-        Fr a = zn;
-        for (uint32_t i = 0; i < per; i++) { ti[i] = Fr::inv(a - Fr::one()); a = a * wn; }
+        std::vector<Fr> ti(nc), node(nc);
+        for (uint32_t j = 0; j < nc; j++) {
+            node[j] = Fr::pow_u64(cj[j], n);
+            ti[j] = Fr::inv(node[j] - Fr::one());
+        }
         pk->t_inv = pk->dupload(ti);
+        std::vector<Fr> A((size_t)nc * nc), I((size_t)nc * nc, Fr::zero());
+        for (uint32_t j = 0; j < nc; j++) {
+            Fr p = Fr::one();
+            for (uint32_t m = 0; m < nc; m++) { A[(size_t)j * nc + m] = p; p = p * node[j]; }
+            I[(size_t)j * nc + j] = Fr::one();
+        }
+        for (uint32_t col = 0; col < nc; col++) {
+            uint32_t piv = col;
+            while (piv < nc && A[(size_t)piv * nc + col].is_zero()) piv++;
+            SHP_REQUIRE(piv < nc, SHP_ERR_INTERNAL, "keygen: singular coset matrix");
+            for (uint32_t c = 0; c < nc; c++) {
+                std::swap(A[(size_t)piv * nc + c], A[(size_t)col * nc + c]);
+                std::swap(I[(size_t)piv * nc + c], I[(size_t)col * nc + c]);
+            }
+            const Fr pinv = Fr::inv(A[(size_t)col * nc + col]);
+            for (uint32_t c = 0; c < nc; c++) {
+                A[(size_t)col * nc + c] = A[(size_t)col * nc + c] * pinv;
+                I[(size_t)col * nc + c] = I[(size_t)col * nc + c] * pinv;
+            }
+            for (uint32_t r = 0; r < nc; r++) {
+                if (r == col) continue;
+                const Fr f = A[(size_t)r * nc + col];
+                if (f.is_zero()) continue;
+                for (uint32_t c = 0; c < nc; c++) {
+                    A[(size_t)r * nc + c] = A[(size_t)r * nc + c] - f * A[(size_t)col * nc + c];
+                    I[(size_t)r * nc + c] = I[(size_t)r * nc + c] - f * I[(size_t)col * nc + c];
+                }
+            }
+        }
+        pk->vinv = pk->dupload(I);                 // h_m = sum_j vinv[m][j] * y_j
     }
     pk->consts = pk->dupload(P.consts);
     pk->gate_prog = pk->dupload(P.gate_prog);
@@ -585,7 +639,7 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     SHP_HIP(hipStreamCreateWithFlags(&pr->st, hipStreamNonBlocking));
     pr->own_stream = true;
     const PlanData& P = pk->plan;
-    const uint32_t n = pk->n, ne = pk->ne, NV = pk->NV, L = (uint32_t)P.lookups.size(), S = P.num_sets;
+    const uint32_t n = pk->n, ne = pk->nq, NV = pk->NV, L = (uint32_t)P.lookups.size(), S = P.num_sets;   // ne: quotient domain
     pr->vals = pr->dalloc<Fr>((size_t)(NV + 1) * n);
     // unassigned witness rows are never uploaded; on the prover's own stream (non-blocking: the null stream's
     // memset would not be ordered before the first proof's uploads)
@@ -702,10 +756,10 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     const PlanData& P = pk->plan;
     hipStream_t st = pr->st;
     SHP_HIP(hipSetDevice(ctx->device));                 // the caller may be any host thread (pool workers, FFI callers)
-    const uint32_t n = pk->n, ne = pk->ne, k = P.k, ek = P.ext_k, bf = P.bf, u = P.usable;
+    const uint32_t n = pk->n, ne = pk->nq, k = P.k, bf = P.bf, u = P.usable;   // ne = nc * n: the quotient domain
     const uint32_t A = P.num_advice, L = (uint32_t)P.lookups.size(), S = P.num_sets, NV = pk->NV;
     const uint32_t PC = (uint32_t)P.perm_cols.size(), F = P.num_fixed;
-    const uint32_t estep = 1u << (ek - k), nb = bf + 1;
+    const uint32_t nb = bf + 1;
     SHP_REQUIRE(n_inputs == P.n_winputs, SHP_ERR_INVALID_ARG, "prove: wrong number of witness inputs");
     const uint32_t I_PIN = A, I_PZ = A + 2 * L, I_LZ = A + 2 * L + S, I_INST = NV;
     auto V = [&](uint32_t idx) { return pr->vals + (size_t)idx * n; };
@@ -812,13 +866,13 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         a.adv_base = V(0); a.adv_stride = n;
         a.fix_base = pk->fixed_vals; a.fix_stride = n;
         a.inst_base = V(I_INST);
-        a.size_mask = n - 1; a.rot_step = 1;
+        a.size_mask = n - 1; a.rot_step = 1; a.hi_mask = 0;
     };
     auto extended_domain = [&](ProgArgs& a) {
         a.adv_base = CS(0); a.adv_stride = ne;
         a.fix_base = pk->fixed_cos; a.fix_stride = ne;
         a.inst_base = CS(I_INST);
-        a.size_mask = ne - 1; a.rot_step = estep;
+        a.size_mask = n - 1; a.rot_step = 1; a.hi_mask = ~(n - 1);
     };
     pc.mark("advice_msm");
     // ---- P3: lookups -- compress, permute, commit
@@ -909,12 +963,12 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     // ---- P9: coefficient forms and cosets of everything committed so far (+ instance column)
     NttOpts inv;
     inv.inverse = true;
-    NttOpts ext;
-    ext.in_len = n; ext.in_stride = n; ext.pre_pattern = 1;
+    NttOpts ext;                                         // values on the nc cosets of the quotient domain
+    ext.twist = pk->twist; ext.twist_count = pk->nc;
     ntt_launch(ctx, pr->vals, pr->polys, k, NV + 1, inv, st, pr->ntt_tmp);
-    ntt_launch(ctx, pr->polys, pr->cos, ek, NV + 1, ext, st, pr->ntt_tmp);
+    ntt_launch(ctx, pr->polys, pr->cos, k, (NV + 1) * pk->nc, ext, st, pr->ntt_tmp);
     // ---- P10: quotient
-    const uint32_t ebs = std::min<uint32_t>(256, ne);     // element-wise kernels over the extended domain (ne >= 128)
+    const uint32_t ebs = std::min<uint32_t>(256, n);      // element-wise kernels over the quotient domain (n >= 64)
     extended_domain(pa);
     pa.mult = y; pa.acc_in = nullptr;
     pa.prog = pk->gate_prog; pa.n_instr = (uint32_t)P.gate_prog.size(); pa.nslots = P.gate_slots;
@@ -932,7 +986,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         }
         q.pz = CS(I_PZ);
         q.l0 = pk->l0; q.l_last = pk->l_last; q.l_active = pk->l_active;
-        q.n_sets = S; q.mask = ne - 1; q.step = estep; q.rot_last = P.rot_last; q.y = y; q.h = pr->h;
+        q.n_sets = S; q.mask = n - 1; q.stride = ne; q.rot_last = P.rot_last; q.y = y; q.h = pr->h;
         hipLaunchKernelGGL(perm_quotient_kernel, dim3(ne / ebs), dim3(ebs), 0, st, q);
     }
     for (uint32_t l = 0; l < L; l++) {
@@ -949,13 +1003,13 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         q.z = CS(I_LZ + l); q.pin = CS(I_PIN + 2 * l); q.ptab = CS(I_PIN + 2 * l + 1);
         q.ain = pr->aux_ext; q.stab = pr->aux_ext + ne;
         q.l0 = pk->l0; q.l_last = pk->l_last; q.l_active = pk->l_active;
-        q.mask = ne - 1; q.step = estep; q.y = y; q.beta = beta; q.gamma = gamma; q.h = pr->h;
+        q.mask = n - 1; q.y = y; q.beta = beta; q.gamma = gamma; q.h = pr->h;
         hipLaunchKernelGGL(lookup_quotient_kernel, dim3(ne / ebs), dim3(ebs), 0, st, q);
     }
-    hipLaunchKernelGGL(scale_periodic_kernel, dim3(ne / ebs), dim3(ebs), 0, st, pr->h, pk->t_inv, estep - 1);
-    NttOpts back;
-    back.inverse = true; back.post_pattern = 1;
-    ntt_launch(ctx, pr->h, pr->h, ek, 1, back, st, pr->ntt_tmp);
+    hipLaunchKernelGGL(scale_periodic_kernel, dim3(ne / ebs), dim3(ebs), 0, st, pr->h, pk->t_inv, k);
+    // per-coset interpolants, then the nc x nc solve per coefficient: pr->h becomes the quotient pieces [nc][n]
+    ntt_launch(ctx, pr->h, pr->h, k, pk->nc, inv, st, pr->ntt_tmp);
+    hipLaunchKernelGGL(coset_combine_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->h, pk->cinv, pk->vinv, pk->nc, n);
     const uint32_t npieces = P.degree - 1;
     ctr += npieces;                                      // one (unused) blind per quotient piece
     commit(srs->msm_g, pr->h, npieces, pts.data());

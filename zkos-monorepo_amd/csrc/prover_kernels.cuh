@@ -39,7 +39,9 @@ struct ProgArgs {
     const Fr* adv_base; size_t adv_stride;
     const Fr* fix_base; size_t fix_stride;
     const Fr* inst_base;
-    uint32_t size_mask, rot_step;
+    // row r, rotation q.rot -> (r & hi_mask) | ((r + q.rot * rot_step) & size_mask): hi_mask = 0 on the Lagrange
+    // domain; on the quotient domain (cosets c_j * H laid out coset-major) the coset index stays, the row moves
+    uint32_t size_mask, rot_step, hi_mask;
     Fr mult;
     const Fr* acc_in;
     Fr* out;
@@ -71,19 +73,19 @@ __global__ __launch_bounds__(PROG_THREADS) void prog_fold_kernel(ProgArgs a) {
             case OP_CONST: put(in.dst, ld(a.consts + in.a)); break;
             case OP_ADV: {
                 Query q = a.adv_q[in.a];
-                uint32_t r = (row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask;
+                uint32_t r = (row & a.hi_mask) | ((row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask);
                 put(in.dst, ld(a.adv_base + (size_t)q.col * a.adv_stride + r));
                 break;
             }
             case OP_FIX: {
                 Query q = a.fix_q[in.a];
-                uint32_t r = (row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask;
+                uint32_t r = (row & a.hi_mask) | ((row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask);
                 put(in.dst, ld(a.fix_base + (size_t)q.col * a.fix_stride + r));
                 break;
             }
             case OP_INST: {
                 Query q = a.inst_q[in.a];
-                uint32_t r = (row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask;
+                uint32_t r = (row & a.hi_mask) | ((row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask);
                 put(in.dst, ld(a.inst_base + r));
                 break;
             }
@@ -134,19 +136,19 @@ __global__ __launch_bounds__(PROG_THREADS) void prog_fold_reg_kernel(ProgArgs a)
             case OP_CONST: r = ld(a.consts + in.a); break;
             case OP_ADV: {
                 Query q = a.adv_q[in.a];
-                uint32_t rr = (row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask;
+                uint32_t rr = (row & a.hi_mask) | ((row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask);
                 r = ld(a.adv_base + (size_t)q.col * a.adv_stride + rr);
                 break;
             }
             case OP_FIX: {
                 Query q = a.fix_q[in.a];
-                uint32_t rr = (row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask;
+                uint32_t rr = (row & a.hi_mask) | ((row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask);
                 r = ld(a.fix_base + (size_t)q.col * a.fix_stride + rr);
                 break;
             }
             case OP_INST: {
                 Query q = a.inst_q[in.a];
-                uint32_t rr = (row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask;
+                uint32_t rr = (row & a.hi_mask) | ((row + (uint32_t)(q.rot * (int32_t)a.rot_step)) & a.size_mask);
                 r = ld(a.inst_base + rr);
                 break;
             }
@@ -601,10 +603,11 @@ __global__ __launch_bounds__(1024) void lookup_permute_kernel(const Fr* a_all, c
 
 // ------------------------------------------------------------------ quotient terms (extended domain)
 struct PermQArgs {
-    PermArgs p;                 // col = cosets, sigma = sigma cosets, xs = zeta * omega_ext^i
-    const Fr* pz;               // [n_sets][ne]
+    PermArgs p;                 // col = cosets, sigma = sigma cosets, xs = the points c_j * omega^t
+    const Fr* pz;               // [n_sets][stride]
     const Fr* l0; const Fr* l_last; const Fr* l_active;
-    uint32_t n_sets, mask, step;
+    uint32_t n_sets, mask;      // mask = n - 1: rotations move inside a coset (index = j * n + t)
+    size_t stride;
     int32_t rot_last;
     Fr y;
     Fr* h;
@@ -612,17 +615,18 @@ struct PermQArgs {
 
 __global__ __launch_bounds__(256, 2) void perm_quotient_kernel(PermQArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t ne = (size_t)a.mask + 1;
+    const size_t ne = a.stride;
+    const uint32_t base = i & ~a.mask;
     Fr h = ld(a.h + i);
     const Fr l0 = ld(a.l0 + i), ll = ld(a.l_last + i), la = ld(a.l_active + i);
     const Fr one = Fr::one();
     h = h * a.y + l0 * (one - ld(a.pz + i));
     Fr zl = ld(a.pz + (size_t)(a.n_sets - 1) * ne + i);
     h = h * a.y + ll * (Fr::sqr(zl) - zl);
-    const uint32_t ilast = (i + (uint32_t)(a.rot_last * (int32_t)a.step)) & a.mask;
+    const uint32_t ilast = base | ((i + (uint32_t)a.rot_last) & a.mask);
     for (uint32_t s = 1; s < a.n_sets; s++)
         h = h * a.y + l0 * (ld(a.pz + (size_t)s * ne + i) - ld(a.pz + (size_t)(s - 1) * ne + ilast));
-    const uint32_t inext = (i + a.step) & a.mask;
+    const uint32_t inext = base | ((i + 1) & a.mask);
     const Fr x = ld(a.p.xs + i);
     for (uint32_t s = 0; s < a.n_sets; s++) {
         Fr left = ld(a.pz + (size_t)s * ne + inext), right = ld(a.pz + (size_t)s * ne + i);
@@ -641,7 +645,7 @@ struct LookupQArgs {
     const Fr* z; const Fr* pin; const Fr* ptab;       // cosets
     const Fr* ain; const Fr* stab;                     // theta-compressed input / table on the coset
     const Fr* l0; const Fr* l_last; const Fr* l_active;
-    uint32_t mask, step;
+    uint32_t mask;                                     // n - 1 (coset-major quotient domain)
     Fr y, beta, gamma;
     Fr* h;
 };
@@ -651,7 +655,7 @@ __global__ void lookup_quotient_kernel(LookupQArgs a) {
     Fr h = ld(a.h + i);
     const Fr l0 = ld(a.l0 + i), ll = ld(a.l_last + i), la = ld(a.l_active + i);
     const Fr z = ld(a.z + i), ap = ld(a.pin + i), sp = ld(a.ptab + i);
-    const uint32_t inext = (i + a.step) & a.mask, iprev = (i - a.step) & a.mask;
+    const uint32_t base = i & ~a.mask, inext = base | ((i + 1) & a.mask), iprev = base | ((i - 1) & a.mask);
     h = h * a.y + l0 * (Fr::one() - z);
     h = h * a.y + ll * (Fr::sqr(z) - z);
     Fr lhs = ld(a.z + inext) * (ap + a.beta) * (sp + a.gamma);
@@ -663,9 +667,30 @@ __global__ void lookup_quotient_kernel(LookupQArgs a) {
     st(a.h + i, h);
 }
 
-__global__ void scale_periodic_kernel(Fr* h, const Fr* t_inv, uint32_t period_mask) {
+// h on coset j (rows j * n .. j * n + n - 1) times 1 / (c_j^n - 1): the vanishing polynomial is constant on a coset
+__global__ void scale_periodic_kernel(Fr* h, const Fr* t_inv, uint32_t log_n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    st(h + i, ld(h + i) * ld(t_inv + (i & period_mask)));
+    st(h + i, ld(h + i) * ld(t_inv + (i >> log_n)));
+}
+
+// Quotient pieces from the per-coset interpolants.  q_j = iNTT of h on coset c_j * H, so q_j[t] = c_j^t * sum_m
+// h_m[t] * (c_j^n)^m with h = sum_m X^(m n) h_m: for every coefficient index t one nc x nc Vandermonde solve
+// (matrix inverse precomputed at keygen), in place: h[m][t] <- sum_j vinv[m][j] * q_j[t] * c_j^-t
+constexpr uint32_t MAX_COSETS = 16;
+__global__ void coset_combine_kernel(Fr* h, const Fr* cinv, const Fr* vinv, uint32_t nc, uint32_t n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Fr y[MAX_COSETS];
+#pragma unroll
+    for (uint32_t j = 0; j < MAX_COSETS; j++)
+        if (j < nc) y[j] = ld(h + (size_t)j * n + t) * ld(cinv + (size_t)j * n + t);
+    for (uint32_t m = 0; m < nc; m++) {
+        Fr acc = Fr::zero();
+#pragma unroll
+        for (uint32_t j = 0; j < MAX_COSETS; j++)
+            if (j < nc) acc = acc + ld(vinv + m * nc + j) * y[j];
+        st(h + (size_t)m * n + t, acc);
+    }
 }
 
 // ------------------------------------------------------------------ evaluations
