@@ -1007,12 +1007,15 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         hipLaunchKernelGGL(lookup_quotient_kernel, dim3(ne / ebs), dim3(ebs), 0, st, q);
     }
     hipLaunchKernelGGL(scale_periodic_kernel, dim3(ne / ebs), dim3(ebs), 0, st, pr->h, pk->t_inv, k);
-    // per-coset interpolants, then the nc x nc solve per coefficient: pr->h becomes the quotient pieces [nc][n]
+    // per-coset interpolants, then the nc x nc solve per coefficient: the quotient pieces [nc][n] (in the buffer
+    // the lookup compression no longer needs)
     ntt_launch(ctx, pr->h, pr->h, k, pk->nc, inv, st, pr->ntt_tmp);
-    hipLaunchKernelGGL(coset_combine_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->h, pk->cinv, pk->vinv, pk->nc, n);
+    Fr* const hp = pr->aux_ext;
+    hipLaunchKernelGGL(coset_combine_kernel, dim3(ceil_div(n, 256), pk->nc), dim3(256), 0, st, pr->h, pk->cinv, pk->vinv,
+                       pk->nc, n, hp);
     const uint32_t npieces = P.degree - 1;
     ctr += npieces;                                      // one (unused) blind per quotient piece
-    commit(srs->msm_g, pr->h, npieces, pts.data());
+    commit(srs->msm_g, hp, npieces, pts.data());
     for (uint32_t i = 0; i < npieces; i++) tr.write_point(pts[i].x, pts[i].y);
     pc.mark("quotient_msm");
     // ---- P11: evaluations
@@ -1033,7 +1036,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
                            pr->points, n, per, pr->pw);
     }
     const Fr xn = Fr::pow_u64(x, n);
-    hipLaunchKernelGGL(combine_pieces_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->h, n, npieces, xn, pr->hx);
+    hipLaunchKernelGGL(combine_pieces_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, hp, n, npieces, xn, pr->hx);
     // the eval list in proof order, then h(x) (needed only for the opening argument)
     std::vector<EvalJob> jobs;
     std::vector<std::pair<PolyKey, int32_t>> job_key;

@@ -675,22 +675,16 @@ __global__ void scale_periodic_kernel(Fr* h, const Fr* t_inv, uint32_t log_n) {
 
 // Quotient pieces from the per-coset interpolants.  q_j = iNTT of h on coset c_j * H, so q_j[t] = c_j^t * sum_m
 // h_m[t] * (c_j^n)^m with h = sum_m X^(m n) h_m: for every coefficient index t one nc x nc Vandermonde solve
-// (matrix inverse precomputed at keygen), in place: h[m][t] <- sum_j vinv[m][j] * q_j[t] * c_j^-t
+// (matrix inverse precomputed at keygen): pieces[m][t] = sum_j vinv[m][j] * q_j[t] * c_j^-t
 constexpr uint32_t MAX_COSETS = 16;
-__global__ void coset_combine_kernel(Fr* h, const Fr* cinv, const Fr* vinv, uint32_t nc, uint32_t n) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+// grid (n / block, nc): one thread per (piece m, coefficient t) -- 2 nc products deep instead of nc^2 + nc
+__global__ void coset_combine_kernel(const Fr* q, const Fr* cinv, const Fr* vinv, uint32_t nc, uint32_t n, Fr* pieces) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     if (t >= n) return;
-    Fr y[MAX_COSETS];
-#pragma unroll
-    for (uint32_t j = 0; j < MAX_COSETS; j++)
-        if (j < nc) y[j] = ld(h + (size_t)j * n + t) * ld(cinv + (size_t)j * n + t);
-    for (uint32_t m = 0; m < nc; m++) {
-        Fr acc = Fr::zero();
-#pragma unroll
-        for (uint32_t j = 0; j < MAX_COSETS; j++)
-            if (j < nc) acc = acc + ld(vinv + m * nc + j) * y[j];
-        st(h + (size_t)m * n + t, acc);
-    }
+    Fr acc = Fr::zero();
+    for (uint32_t j = 0; j < nc; j++)
+        acc = acc + ld(vinv + m * nc + j) * (ld(q + (size_t)j * n + t) * ld(cinv + (size_t)j * n + t));
+    st(pieces + (size_t)m * n + t, acc);
 }
 
 // ------------------------------------------------------------------ evaluations
