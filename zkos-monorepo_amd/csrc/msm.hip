@@ -752,10 +752,10 @@ static uint32_t direct_windows(uint32_t c) {
     return W;
 }
 
-// largest c in [8, 13] whose full multiples table fits the budget (0 = none: use buckets)
+// largest c in [8, 14] whose full multiples table fits the budget (0 = none: use buckets)
 static uint32_t pick_direct_window(size_t n) {
     const double budget = direct_budget_gib() * 1073741824.0;
-    for (uint32_t c = 13; c >= 8; c--) {
+    for (uint32_t c = 14; c >= 8; c--) {
         double bytes = (double)n * direct_windows(c) * (double)(1u << (c - 1)) * sizeof(G1Affine);
         if (bytes <= budget) return c;
     }
