@@ -202,8 +202,9 @@ int32_t shp_prove(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, c
                   size_t instances_cap);
 /* Host threads the lane uses for the witness program (the reference's `synthesize`, rayon in its
  * multithreading feature): the program is cut into independent tasks once per lane (Poseidon2
- * permutations of the Merkle levels run side by side).  Default 4 (env SHP_WITNESS_THREADS); a
- * proving pool with more than 4 lanes sets 1 -- throughput does not need it, latency does. */
+ * permutations of the Merkle levels run side by side).  Default 8 (env SHP_WITNESS_THREADS); a
+ * proving pool divides them over its lanes and sets 1 above 4 lanes -- throughput does not need
+ * them, latency does. */
 int32_t shp_prover_witness_threads(shp_prover* p, uint32_t threads);
 /* Scheduling bias of a lane: 0 = latency (default: short per-lane addition chains in the commitment
  * kernels, so a lone proof fills the chip), 1 = throughput (long chains, least reduction work; what a

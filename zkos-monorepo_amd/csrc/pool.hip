@@ -99,6 +99,7 @@ int32_t shp_pool_create(shp_pk* pk, uint32_t lanes, uint32_t queue_cap, shp_pool
                 throw shp::Error(rc, std::string("pool_create: ") + shp_last_error());
             }
             if (lanes > 4) (void)shp_prover_mode(pr, 1);   // many lanes: one host thread each, long MSM chains
+            else if (lanes > 1) (void)shp_prover_witness_threads(pr, 8 / lanes);   // a few lanes share the helper threads' cores
             p->lanes.push_back(pr);
         }
         // opt-in (SHP_POOL_COMBINE=1): on one MI355X the pool is not limited by the size of its MSM launches --

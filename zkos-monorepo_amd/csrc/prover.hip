@@ -484,6 +484,12 @@ struct WitnessSchedule {
             }
             // program order inside a thread (tasks of one level are independent, this is for locality)
             for (auto& v : plan[lv]) std::sort(v.begin(), v.end(), [](const Range& a, const Range& b) { return a.lo < b.lo; });
+            if (getenv("SHP_PHASE_TRACE")) {
+                uint64_t mx = 0, sum = 0;
+                for (uint64_t l : load) { mx = std::max(mx, l); sum += l; }
+                fprintf(stderr, "[witness] level %u: %zu tasks, %llu ops, busiest thread %llu\n", lv, at.size(),
+                        (unsigned long long)sum, (unsigned long long)mx);
+            }
         }
     }
 };
@@ -532,7 +538,7 @@ struct WitnessWorkers {
             // spin for a while (back-to-back proofs), then sleep
             auto t0 = std::chrono::steady_clock::now();
             while (gen.load(std::memory_order_acquire) == seen) {
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {   // longer than one proof
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen; });
                     break;
@@ -684,7 +690,7 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->wscratch.assign(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
     {
         const char* e = getenv("SHP_WITNESS_THREADS");
-        set_witness_threads(pr.get(), e && *e ? (uint32_t)atoi(e) : 4);
+        set_witness_threads(pr.get(), e && *e ? (uint32_t)atoi(e) : 8);   // 14 independent permutations: 215 us at 4, 175 at 8
     }
     *out = pr.release();
 }
