@@ -423,34 +423,106 @@ struct alignas(16) Fp {
     // 1/a for a in Montgomery form; 0 -> 0.  Binary extended Euclid on the raw limbs (shift /
     // subtract only: ~1.5 * 254 short iterations instead of ~380 dependent Montgomery products),
     // then one product by R^3 to return to Montgomery form: (aR)^-1 * R^3 / R = a^-1 R.
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // Host inversion: Kaliski's almost-inverse on four 64-bit limbs, every run of trailing zero bits shifted out at
+    // once (the same recurrence as inv_kaliski below), then the 2^k correction by Montgomery products with one-bit
+    // constants.  ~3 us instead of ~9 for the bit-at-a-time extended Euclid it replaces: the prover inverts on the
+    // host after every commitment phase (normalisation of the MSM sums) with the GPU idle.
+    static Fp inv_host(const Fp& a) {
+        typedef unsigned __int128 u128;
+        uint64_t u[4], v[4], r[4] = {0, 0, 0, 0}, s[4] = {1, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            u[i] = (uint64_t)PR::p(2 * i) | ((uint64_t)PR::p(2 * i + 1) << 32);
+            v[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+        }
+        auto shr = [](uint64_t* x, unsigned t) {           // 1 <= t <= 63
+            x[0] = (x[0] >> t) | (x[1] << (64 - t));
+            x[1] = (x[1] >> t) | (x[2] << (64 - t));
+            x[2] = (x[2] >> t) | (x[3] << (64 - t));
+            x[3] >>= t;
+        };
+        auto shl = [](uint64_t* x, unsigned t) {
+            x[3] = (x[3] << t) | (x[2] >> (64 - t));
+            x[2] = (x[2] << t) | (x[1] >> (64 - t));
+            x[1] = (x[1] << t) | (x[0] >> (64 - t));
+            x[0] <<= t;
+        };
+        auto tz = [](uint64_t low) -> unsigned { return low ? (unsigned)__builtin_ctzll(low) : 63u; };
+        auto sub = [](uint64_t* x, const uint64_t* y) {    // x -= y, returns the borrow
+            u128 b = 0;
+            for (int i = 0; i < 4; i++) {
+                u128 d = (u128)x[i] - y[i] - b;
+                x[i] = (uint64_t)d;
+                b = (d >> 64) & 1;
+            }
+            return (uint64_t)b;
+        };
+        auto add = [](uint64_t* x, const uint64_t* y) {
+            u128 c = 0;
+            for (int i = 0; i < 4; i++) {
+                c += (u128)x[i] + y[i];
+                x[i] = (uint64_t)c;
+                c >>= 64;
+            }
+        };
+        auto geq = [](const uint64_t* x, const uint64_t* y) {
+            for (int i = 3; i >= 0; i--)
+                if (x[i] != y[i]) return x[i] > y[i];
+            return true;
+        };
+        auto is_zero4 = [](const uint64_t* x) { return (x[0] | x[1] | x[2] | x[3]) == 0; };
+        uint32_t k = 0;
+        while (!is_zero4(v) && k < 600) {
+            if (!(u[0] & 1)) {
+                const unsigned t = tz(u[0]);
+                shr(u, t); shl(s, t); k += t;
+            } else if (!(v[0] & 1)) {
+                const unsigned t = tz(v[0]);
+                shr(v, t); shl(r, t); k += t;
+            } else if (geq(v, u)) {
+                sub(v, u);
+                add(s, r);
+                if (is_zero4(v)) {                         // u == v == 1: the last step of the plain algorithm
+                    shl(r, 1);
+                    k += 1;
+                    break;
+                }
+                const unsigned t = tz(v[0]);
+                shr(v, t); shl(r, t); k += t;
+            } else {
+                sub(u, v);
+                add(r, s);
+                const unsigned t = tz(u[0]);
+                shr(u, t); shl(s, t); k += t;
+            }
+        }
+        uint64_t pm[4];
+        for (int i = 0; i < 4; i++) pm[i] = (uint64_t)PR::p(2 * i) | ((uint64_t)PR::p(2 * i + 1) << 32);
+        if (geq(r, pm)) sub(r, pm);
+        sub(pm, r);                                        // (aR)^-1 2^k mod p
+        Fp x;
+        for (int i = 0; i < 4; i++) { x.l[2 * i] = (uint32_t)pm[i]; x.l[2 * i + 1] = (uint32_t)(pm[i] >> 32); }
+        Fp r3;
+        for (int i = 0; i < 8; i++) r3.l[i] = PR::r3(i);
+        x = mul(x, r3);
+        const uint32_t k1 = k < 256 ? k : 256, k2 = k - k1;
+        auto pow2 = [](uint32_t e) {
+            Fp c = zero();
+            c.l[e >> 5] = 1u << (e & 31);
+            return c;
+        };
+        x = mul(x, pow2(256 - k1));
+        if (k2) x = mul(x, pow2(256 - k2));
+        return x;
+    }
+#endif
+
     static SHP_HD Fp inv(const Fp& a) {
         if (a.is_zero()) return a;
 #if defined(__HIP_DEVICE_COMPILE__)
         return inv_kaliski(a);
 #else
-        Fp u = a, v = modulus();
-        Fp x1 = zero(), x2 = zero();
-        x1.l[0] = 1;
-        for (int guard = 0; guard < 1100; guard++) {
-            if (u.raw_is_one() || v.raw_is_one()) break;
-            if (!(u.l[0] & 1u)) {
-                u.raw_shr1();
-                x1.raw_half_mod();
-            } else if (!(v.l[0] & 1u)) {
-                v.raw_shr1();
-                x2.raw_half_mod();
-            } else if (!raw_lt(u, v)) {
-                u.raw_sub(v);
-                x1 = sub(x1, x2);
-            } else {
-                v.raw_sub(u);
-                x2 = sub(x2, x1);
-            }
-        }
-        Fp r3;
-#pragma unroll
-        for (int i = 0; i < 8; i++) r3.l[i] = PR::r3(i);
-        return mul(u.raw_is_one() ? x1 : x2, r3);
+        return inv_host(a);
 #endif
     }
 
