@@ -778,15 +778,29 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     Fr* const sc_bpre = pr->sc_tot + (size_t)2 * pr->sc_cnt * SCAN_THREADS;
     Fr* const sc_bsuf = pr->sc_tot + (size_t)3 * pr->sc_cnt * SCAN_THREADS;
     Fr* const sc_inv = pr->sc_tot + (size_t)4 * pr->sc_cnt * SCAN_THREADS;
-    auto product_scans = [&](const Fr* a, const Fr* b, uint32_t cnt) {
+    // A lone proof (latency mode) inverts the totals on the host: the product goes to pinned memory, the stream is
+    // drained, the inverses come back as kernel arguments.  Pool lanes keep the inversion on the device (one lane,
+    // 55 us, but no extra round trip while fifteen other lanes fill the GPU).
+    auto product_scans = [&](const Fr* a, const Fr* b, uint32_t cnt) -> InvList {
+        InvList il;
+        il.n = 0;
+        const bool on_host = !pr->throughput && cnt <= INV_LIST_MAX;
+        Fr* totals = on_host ? (Fr*)pr->stage_alloc(cnt * sizeof(Fr)) : nullptr;
         hipLaunchKernelGGL(scan_local_kernel, dim3(snb, cnt), dim3(sbs), 0, st, a, b, n, pr->sc_pre, pr->sc_suf, sc_ta, sc_tb);
-        hipLaunchKernelGGL(scan_totals_kernel, dim3(cnt), dim3(SCAN_THREADS), 0, st, sc_ta, sc_tb, snb, sc_bpre, sc_bsuf, sc_inv);
+        hipLaunchKernelGGL(scan_totals_kernel, dim3(cnt), dim3(SCAN_THREADS), 0, st, sc_ta, sc_tb, snb, sc_bpre, sc_bsuf, sc_inv,
+                           totals);
+        if (on_host) {
+            SHP_HIP(hipStreamSynchronize(st));
+            il.n = cnt;
+            for (uint32_t i = 0; i < cnt; i++) il.v[i] = Fr::inv(totals[i]);
+        }
+        return il;
     };
     auto batch_invert = [&](const Fr* in, Fr* out, uint32_t cnt) {
         pr->timers.begin(KID_BATCH_INVERT, st);
-        product_scans(in, in, cnt);
+        const InvList il = product_scans(in, in, cnt);
         hipLaunchKernelGGL(batch_invert_apply_kernel, dim3(snb, cnt), dim3(sbs), 0, st, pr->sc_pre, pr->sc_suf, sc_bpre, sc_bsuf,
-                           sc_inv, n, out);
+                           sc_inv, n, out, il);
         pr->timers.end(st);
     };
 
@@ -952,9 +966,9 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     h2d(pr->blinds, hb.data(), hb.size() * sizeof(Fr));
     pr->timers.begin(KID_GRAND_PRODUCT, st);
     if (S + L) {                                           // a plan may have neither a permutation nor a lookup
-        product_scans(pr->num, pr->den, S + L);
+        const InvList il = product_scans(pr->num, pr->den, S + L);
         hipLaunchKernelGGL(grand_product_apply_kernel, dim3(snb, S + L), dim3(sbs), 0, st, pr->sc_pre, pr->sc_suf, sc_bpre,
-                           sc_bsuf, sc_inv, n, S, u, bf, V(I_PZ), (size_t)n, pr->blinds);
+                           sc_bsuf, sc_inv, n, S, u, bf, V(I_PZ), (size_t)n, pr->blinds, il);
     }
     pr->timers.end(st);
     SHP_REQUIRE(ctr == ctr_rand, SHP_ERR_INTERNAL, "prove: blinding stream position of the random polynomial");

@@ -307,8 +307,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_local_kernel(const Fr* a, c
 
 // grid (cnt), 256 threads, nb = n / 256 <= 256 block totals per product.
 // bpre_a[k] = prod_{j<k} tot_a[j]; bsuf_b[k] = prod_{j>k} tot_b[j]; inv_b = 1 / prod_j tot_b[j]
+// total_out (pinned host memory) non-null: the product of all b goes there instead of its inverse into inv_b --
+// a lone proof inverts it on the host (3 us + a stream round trip) rather than on one GPU lane (55 us)
 __global__ __launch_bounds__(SCAN_THREADS) void scan_totals_kernel(const Fr* tot_a, const Fr* tot_b, uint32_t nb, Fr* bpre_a,
-                                                                   Fr* bsuf_b, Fr* inv_b) {
+                                                                   Fr* bsuf_b, Fr* inv_b, Fr* total_out) {
     __shared__ Fr sh[SCAN_THREADS];
     const uint32_t t = threadIdx.x, p = blockIdx.x;
     if (nb <= 64) {
@@ -330,7 +332,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_totals_kernel(const Fr* tot
             st(bpre_a + (size_t)p * nb + t, ea);
             st(bsuf_b + (size_t)p * nb + t, eb);
         }
-        if (t == 0) st(inv_b + p, Fr::inv(sb));            // lane 0's inclusive suffix = the product of all b
+        if (t == 0) {                                       // lane 0's inclusive suffix = the product of all b
+            if (total_out) st(total_out + p, sb);
+            else st(inv_b + p, Fr::inv(sb));
+        }
         return;
     }
     const Fr va = t < nb ? ld(tot_a + (size_t)p * nb + t) : Fr::one();
@@ -341,8 +346,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_totals_kernel(const Fr* tot
         st(bpre_a + (size_t)p * nb + t, ea);
         st(bsuf_b + (size_t)p * nb + t, eb);
     }
-    if (t == 0) st(inv_b + p, Fr::inv(vb * eb));
+    if (t == 0) {
+        if (total_out) st(total_out + p, vb * eb);
+        else st(inv_b + p, Fr::inv(vb * eb));
+    }
 }
+
+// inverses of the totals computed on the host travel as kernel arguments (n = 0: read inv_* from device memory)
+constexpr uint32_t INV_LIST_MAX = 8;
+struct InvList {
+    uint32_t n;
+    Fr v[INV_LIST_MAX];
+};
 
 // z[p][i] = c_p * prod_{r<i} num_r / prod_{r<i} den_r for i <= usable, blinding rows after it.
 // Products [0, n_sets) are the chained permutation sets (c_p = prod_{j<p} z_j[usable]); the rest
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_totals_kernel(const Fr* tot
 __global__ __launch_bounds__(SCAN_THREADS) void grand_product_apply_kernel(const Fr* pre_num, const Fr* suf_den, const Fr* bpre,
                                                                           const Fr* bsuf, const Fr* inv_den, uint32_t n,
                                                                           uint32_t n_sets, uint32_t usable, uint32_t bf, Fr* zbase,
-                                                                          size_t zstride, const Fr* blinds) {
+                                                                          size_t zstride, const Fr* blinds, InvList il) {
     const uint32_t p = blockIdx.y, bs = blockDim.x, nb = n / bs;
     const uint32_t i = blockIdx.x * bs + threadIdx.x;
     Fr* z = zbase + (size_t)p * zstride;
@@ -361,7 +376,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void grand_product_apply_kernel(const
     auto zhat = [&](uint32_t q, uint32_t r) {
         const size_t e = (size_t)q * n + r;
         const size_t k = (size_t)q * nb + r / bs;
-        return ld(pre_num + e) * ld(bpre + k) * (ld(suf_den + e) * ld(bsuf + k)) * ld(inv_den + q);
+        return ld(pre_num + e) * ld(bpre + k) * (ld(suf_den + e) * ld(bsuf + k)) * (il.n ? il.v[q] : ld(inv_den + q));
     };
     Fr v = zhat(p, i);
     if (p < n_sets)
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void grand_product_apply_kernel(const
 
 // out[p][i] = 1 / in[p][i] from the scans of `in` against itself
 __global__ __launch_bounds__(SCAN_THREADS) void batch_invert_apply_kernel(const Fr* pre, const Fr* suf, const Fr* bpre, const Fr* bsuf,
-                                                                         const Fr* inv_tot, uint32_t n, Fr* out) {
+                                                                         const Fr* inv_tot, uint32_t n, Fr* out, InvList il) {
     const uint32_t p = blockIdx.y, bs = blockDim.x, nb = n / bs, t = threadIdx.x, lane = t & 63;
     const size_t e = (size_t)p * n + (size_t)blockIdx.x * bs + t;
     const size_t k = (size_t)p * nb + blockIdx.x;
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void batch_invert_apply_kernel(const 
     Fr sn = ld(suf + e);
     Fr se = shfl_down_fr(sn, 1);
     if (lane == 63) se = t + 1 < bs ? ld(suf + e + 1) : Fr::one();
-    st(out + e, ld(pre + e) * ld(bpre + k) * (se * ld(bsuf + k)) * ld(inv_tot + p));
+    st(out + e, ld(pre + e) * ld(bpre + k) * (se * ld(bsuf + k)) * (il.n ? il.v[p] : ld(inv_tot + p)));
 }
 
 // ------------------------------------------------------------------ lookup permutation
