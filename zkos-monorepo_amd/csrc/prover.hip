@@ -1051,7 +1051,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     }
     h2d(pr->points, points.data(), points.size() * sizeof(Fr));
     {
-        uint32_t per = 8;
+        uint32_t per = 1;                                   // one power per thread: the chain is the exponentiation alone
         hipLaunchKernelGGL(powers_kernel, dim3(ceil_div(ceil_div(n, per), 256), (uint32_t)points.size()), dim3(256), 0, st,
                            pr->points, n, per, pr->pw);
     }
@@ -1095,7 +1095,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     h2d(pr->jobs, jobs.data(), jobs.size() * sizeof(EvalJob));
     // the evaluations land in the pinned arena directly (one store per job over PCIe, no copy dispatch)
     Fr* const evals = (Fr*)pr->stage_alloc(jobs.size() * sizeof(Fr));
-    hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)jobs.size()), dim3(256), 0, st, pr->jobs, pr->pw, n, evals);
+    hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)jobs.size()), dim3(EVAL_THREADS), 0, st, pr->jobs, pr->pw, n, evals);
     // Lagrange values of hx and the random polynomial for the evaluation-form opening
     NttOpts fwd;
     ntt_launch(ctx, pr->hx, pr->lag2, k, 2, fwd, st, pr->ntt_tmp);   // out of place: hx | rand_poly are adjacent

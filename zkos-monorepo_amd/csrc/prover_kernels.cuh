@@ -721,19 +721,24 @@ __global__ void powers_kernel(const Fr* points, uint32_t n, uint32_t per, Fr* pw
 struct EvalJob { const Fr* poly; uint32_t point; uint32_t pad; };
 
 // out[job] = sum_i poly[i] * pw[point][i]
-__global__ __launch_bounds__(256) void eval_kernel(const EvalJob* jobs, const Fr* pw, uint32_t n, Fr* out) {
-    __shared__ Fr sh[256];
+// 1024 threads per evaluation: at n = 8192 eight products per thread and a shuffle + LDS reduction (a lone proof's
+// 59 evaluations are 59 workgroups -- the per-thread chain is what the kernel's duration is made of)
+constexpr int EVAL_THREADS = 1024;
+__global__ __launch_bounds__(EVAL_THREADS) void eval_kernel(const EvalJob* jobs, const Fr* pw, uint32_t n, Fr* out) {
+    __shared__ Fr sh[EVAL_THREADS / 64];
     const EvalJob jb = jobs[blockIdx.x];
     const Fr* w = pw + (size_t)jb.point * n;
     Fr acc = Fr::zero();
-    for (uint32_t i = threadIdx.x; i < n; i += 256) acc = acc + ld(jb.poly + i) * ld(w + i);
-    sh[threadIdx.x] = acc;
+    for (uint32_t i = threadIdx.x; i < n; i += EVAL_THREADS) acc = acc + ld(jb.poly + i) * ld(w + i);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc = acc + shfl_down_fr(acc, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    for (uint32_t off = 128; off >= 1; off >>= 1) {
-        if (threadIdx.x < off) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + off];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        Fr s = sh[0];
+        for (int k = 1; k < EVAL_THREADS / 64; k++) s = s + sh[k];
+        st(out + blockIdx.x, s);
     }
-    if (threadIdx.x == 0) st(out + blockIdx.x, sh[0]);
 }
 
 // hx = sum_i x^(n i) piece_i  (Horner over the quotient pieces)
