@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
 #include <string>
 #include <stdexcept>
 #include <vector>
@@ -96,6 +98,26 @@ struct PinnedBuf {
 
 static inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+}  // namespace shp
+
+// stream waits with the time spent in them accounted per thread (SHP_PHASE_TRACE prints host time = total - waits)
+namespace shp {
+inline double& wait_us_accum() {
+    static thread_local double v = 0;
+    return v;
+}
+inline void sync_stream(hipStream_t st) {
+    static const bool trace = getenv("SHP_PHASE_TRACE") != nullptr;
+    if (!trace) {
+        SHP_HIP(hipStreamSynchronize(st));
+        return;
+    }
+    timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    SHP_HIP(hipStreamSynchronize(st));
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    wait_us_accum() += (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3;
+}
 }  // namespace shp
 
 // Cross-lane MSM combiner of a proving pool (implemented in msm.hip, owned by the pool): opaque here

@@ -927,7 +927,7 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
                        ws.pf.as<G1X>(), ws.h_out.as<G1X>());   // straight into pinned host memory: no copy dispatch
     tm->end(st);
     SHP_HIP(hipGetLastError());
-    SHP_HIP(hipStreamSynchronize(st));
+    shp::sync_stream(st);
     tm->collect();
     ws.h_aff.resize(total);
     normalise_batch(ws.h_out.as<G1X>(), (uint32_t)total, ws.h_aff.data());

@@ -736,7 +736,8 @@ struct PhaseClock {
     bool on;
     std::chrono::steady_clock::time_point t0, last;
     std::vector<std::pair<const char*, double>> marks;
-    PhaseClock() : on(getenv("SHP_PHASE_TRACE") != nullptr) { t0 = last = std::chrono::steady_clock::now(); }
+    double wait0;
+    PhaseClock() : on(getenv("SHP_PHASE_TRACE") != nullptr), wait0(shp::wait_us_accum()) { t0 = last = std::chrono::steady_clock::now(); }
     void mark(const char* name) {
         if (!on) return;
         auto now = std::chrono::steady_clock::now();
@@ -746,7 +747,7 @@ struct PhaseClock {
     ~PhaseClock() {
         if (!on) return;
         double tot = std::chrono::duration<double, std::micro>(last - t0).count();
-        fprintf(stderr, "[phases] total %.0f us:", tot);
+        fprintf(stderr, "[phases] total %.0f us (%.0f waiting for the stream):", tot, shp::wait_us_accum() - wait0);
         for (auto& m : marks) fprintf(stderr, " %s=%.0f", m.first, m.second);
         fprintf(stderr, "\n");
     }
@@ -790,7 +791,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         hipLaunchKernelGGL(scan_totals_kernel, dim3(cnt), dim3(SCAN_THREADS), 0, st, sc_ta, sc_tb, snb, sc_bpre, sc_bsuf, sc_inv,
                            totals);
         if (on_host) {
-            SHP_HIP(hipStreamSynchronize(st));
+            sync_stream(st);
             il.n = cnt;
             for (uint32_t i = 0; i < cnt; i++) il.v[i] = Fr::inv(totals[i]);
         }
@@ -1099,7 +1100,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     // Lagrange values of hx and the random polynomial for the evaluation-form opening
     NttOpts fwd;
     ntt_launch(ctx, pr->hx, pr->lag2, k, 2, fwd, st, pr->ntt_tmp);   // out of place: hx | rand_poly are adjacent
-    SHP_HIP(hipStreamSynchronize(st));
+    sync_stream(st);
     std::map<std::pair<PolyKey, int32_t>, Fr> ev;
     for (size_t i = 0; i < jobs.size(); i++) ev[job_key[i]] = evals[i];
     for (size_t i = 0; i < n_proof_evals; i++) tr.write_scalar(evals[i]);
