@@ -212,6 +212,17 @@ def main():
                 traffic = ent["fetch_bytes_per_launch_x2corr"] + ent["write_bytes_per_launch"]
         except OSError:
             pass
+        # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary of this command: start of
+        # the first wave to end of the last, i.e. without the time a launch waits for the other lanes' kernels to
+        # free resources, which the in-stream HIP events do include (they bracket the dispatch, not the execution)
+        rocprof_avg_us = None
+        try:
+            import csv
+            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_bench_kernel_stats.csv"))):
+                if row["Name"].split("(")[0].replace("shp::", "").replace("void ", "") == name + "_kernel":
+                    rocprof_avg_us = float(row["AverageNs"]) * 1e-3
+        except (OSError, KeyError, ValueError):
+            pass
         # VALU issue utilisation of the whole proof: wave-instructions per proof from the committed PMC pass
         # (rocprofv3 --pmc SQ_INSTS_VALU over tools/prove_loop.py --throughput, profiles/README.md), 4 cycles each on
         # one of 1024 SIMDs at 2.4 GHz, against the per-GPU proof rate measured here
@@ -248,7 +259,8 @@ def main():
             "p50_latency_ms": 1e3 * lat[len(lat) // 2] if lat else None,
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "avg_launch_us": 1e6 * avg_s if cnt else None, "launches_per_proof": launches_per_proof,
+                         "avg_launch_us": 1e6 * avg_s if cnt else None, "rocprof_avg_launch_us": rocprof_avg_us,
+                         "launches_per_proof": launches_per_proof,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "k=13 kernels are bound by the 32-bit integer ALU, not by HBM (DESIGN.md section 3); the direct-table "
                                  "MSM deliberately gathers one 64 B table entry per non-zero digit (traffic >> algorithmic bytes) "
