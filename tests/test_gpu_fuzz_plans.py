@@ -185,7 +185,8 @@ def random_plan(seed):
     return b.build(), k, values
 
 
-@pytest.mark.parametrize("seed", list(range(1, 49)))
+# FUZZ_SEEDS=N widens the sweep (a soak run: 400 seeds take ~2 minutes on the GPU box)
+@pytest.mark.parametrize("seed", list(range(1, 1 + int(__import__("os").environ.get("FUZZ_SEEDS", "48")))))
 def test_random_plan_proof_bytes(shp, oracle, gpu_ctx, seed):
     from oracle import plonk as PL
     plan_bytes, k, values = random_plan(seed)
@@ -195,7 +196,7 @@ def test_random_plan_proof_bytes(shp, oracle, gpu_ctx, seed):
     params = shp.Params.synthetic(gpu_ctx, k, TAU)        # carries the G2 half: the native verifier can run
     pk = shp.ProvingKey(gpu_ctx, params, plan_bytes)
     pr = shp.Prover(pk)
-    seed_bytes = bytes([seed]) * 32
+    seed_bytes = bytes([seed % 251 + 1]) * 32
     adv_grid, insts = PL.synthesize(plan, values)
     assert PL.mock_check(plan, adv_grid, insts) == [], "the generated witness must satisfy the generated circuit"
     want = PL.prove(opk, osrs, values, seed_bytes)
