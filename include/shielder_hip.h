@@ -232,6 +232,25 @@ int32_t shp_prover_profile_read(shp_prover* p, uint32_t index, const char** name
 /* poseidon::off_circuit::hash on the host (shielder_bindings/src/hash.rs:17-26): 32-byte LE canonical */
 int32_t shp_poseidon2_hash_host(const uint8_t* inputs_le32, uint32_t arity, uint8_t out_le32[32]);
 
+/* ---- TEE wire protocol (native front door of the serve path) ---------------------------------------
+ * The reference's prover server exchanges serde_json messages whose byte vectors are JSON arrays of
+ * numbers, nested three deep (/root/reference/tee/crates/shielder-prover-common/src/protocol.rs:14-68;
+ * WithdrawProveInputsBytes tee/crates/shielder-prover-tee/src/circuits/withdraw.rs:64-76, deposit.rs:61-72):
+ * 170 KB of frame for 3 KB of witness.  These two calls are the decode and encode halves of
+ * Server::handle_client (server.rs:128-195) for one frame body (the 4-byte length prefix removed). */
+enum { SHP_TEE_PING = 0, SHP_TEE_PUBLIC_KEY = 1, SHP_TEE_GENERATE_PROOF = 2 };          /* Request variants */
+enum { SHP_TEE_NEW_ACCOUNT = 0, SHP_TEE_DEPOSIT = 1, SHP_TEE_WITHDRAW = 2 };            /* CircuitType */
+/* kind: the Request variant.  For GenerateProof: circuit = the payload's CircuitType and witness_le32 = the
+ * circuit's prove() argument vector (32-byte LE canonical field elements; path = height x 7 x 32 bytes),
+ * n_inputs elements.  SHP_ERR_FORMAT for anything serde would reject or vec_to_f would panic on. */
+int32_t shp_tee_decode_request(const uint8_t* json, size_t len, uint32_t height, int32_t* kind, int32_t* circuit,
+                               uint8_t* witness_le32, size_t witness_cap, size_t* n_inputs);
+/* Response::EncryptedProof { proof, pub_inputs } with both fields base64 (the enclave's ECIES layer is out of
+ * scope: they carry the plain proof and the *PubInputsBytes JSON, server.rs:186-193).  out may be NULL to size. */
+int32_t shp_tee_encode_proof_response(int32_t circuit, const uint8_t* proof, size_t proof_len,
+                                      const uint8_t* instances_le32, size_t n_instances, uint8_t* out, size_t cap,
+                                      size_t* out_len);
+
 /* ---- proving pool: the "whole node" serve path ----------------------------------------
  * Replaces the reference's per-connection proving tasks behind a bounded task pool
  * (/root/reference/tee/crates/shielder-prover-tee/src/main.rs:13-20, server.rs:157-195;

@@ -105,3 +105,59 @@ def test_server_round_trips_over_tcp():
     tail = [int.from_bytes(dw[i:i + 32], "little") for i in range(32 * 18, 32 * 22, 32)]
     assert tail == [10**17, 9, 8, 10]                      # value, commitment, nullifier_new, mac_salt
     assert len(be.calls) == 2 and be.calls[0][1] == bytes([7]) * 32 and len(be.calls[0][0]) == 32 * (8 + 14)
+
+
+def test_native_wire_codec_matches_the_python_mirror():
+    """shp_tee_decode_request / shp_tee_encode_proof_response (csrc/wire.hip, host code: runs without a GPU) against the
+    Python mirror of the same messages: same witness vector for Withdraw and Deposit (argument orders differ), unit
+    variants, whitespace, unknown fields ignored as serde does, and every malformed frame rejected with SHP_ERR_FORMAT"""
+    B = importlib.import_module("zkos-monorepo_amd.binding")
+    for ctype, fields in (("Withdraw", S.WITHDRAW_INPUT_FIELDS), ("Deposit", S.DEPOSIT_INPUT_FIELDS)):
+        for height in (1, 2, 13):
+            inputs = make_inputs(height, bump=height)
+            body = json.dumps(make_request(inputs, ctype)).encode()
+            kind, c, wit = B.tee_decode_request(body, height)
+            assert (kind, c) == (B.TEE_GENERATE_PROOF, ctype)
+            assert wit == S.withdraw_witness_bytes(inputs, height, fields)
+    # pretty-printed JSON and an extra field
+    inputs = make_inputs(2)
+    payload = {"circuit_type": "Withdraw", "extra": {"a": [1, "x", None]}, "user_public_key": [], "circuit_inputs":
+               list(json.dumps(dict(inputs, unknown=[1, 2]), indent=1).encode())}
+    body = json.dumps({"GenerateProof": {"payload": list(json.dumps(payload, indent=2).encode())}}, indent=3).encode()
+    assert B.tee_decode_request(body, 2)[2] == S.withdraw_witness_bytes(inputs, 2)
+    assert B.tee_decode_request(b'"Ping"', 2) == (B.TEE_PING, None, None)
+    assert B.tee_decode_request(b'  "TeePublicKey"\n', 2) == (B.TEE_PUBLIC_KEY, None, None)
+
+    def frame(inp, ctype="Withdraw", mutate=None):
+        req = make_request(inp, ctype)
+        return (mutate(req) if mutate else json.dumps(req)).encode()
+
+    bad = []
+    nc = make_inputs(2); nc["value"] = le(R)                                        # not canonical (vec_to_f panics)
+    bad.append(frame(nc))
+    short = make_inputs(2); short["path"] = short["path"][:-1]
+    bad.append(frame(short))
+    missing = make_inputs(2); del missing["mac_salt"]
+    bad.append(frame(missing))
+    big = make_inputs(2); big["id"] = [256] + big["id"][1:]
+    bad.append(frame(big))
+    bad.append(frame(make_inputs(2), "NewAccount"))                                 # no key for it
+    bad.append(frame(make_inputs(2), "Transfer"))
+    bad.append(frame(make_inputs(2)) + b"x")                                        # trailing bytes
+    bad.append(frame(make_inputs(2))[:-3])                                          # truncated
+    bad.append(b'"Pong"')
+    bad.append(b'{"GenerateProof":{}}')
+    bad.append(b'{"Generate":{"payload":[]}}')
+    bad.append(b"")
+    for b in bad:
+        with pytest.raises(B.ShpError) as e:
+            B.tee_decode_request(b, 2)
+        assert e.value.code == 4, b[:60]
+    # response: byte-identical pub_inputs JSON, proof round trip
+    for ctype, pub in (("Withdraw", S.WITHDRAW_PUB_FIELDS), ("Deposit", S.DEPOSIT_PUB_FIELDS)):
+        inst = [R - 1 - i for i in range(8)]
+        for plen in (0, 1, 2, 3, 3456):
+            proof = bytes((7 * i) & 255 for i in range(plen))
+            d = json.loads(B.tee_encode_proof_response(ctype, proof, inst))
+            assert base64.b64decode(d["EncryptedProof"]["proof"]) == proof
+            assert base64.b64decode(d["EncryptedProof"]["pub_inputs"]) == S.withdraw_pub_inputs_json(inst, pub)

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the serve path: Withdraw requests in the TEE wire format
+(4-byte length + JSON, zkos-monorepo_amd/serve.py) over TCP -> native proving pool -> EncryptedProof responses.
+   python tools/serve_bench.py [--clients 48] [--requests 20] [--lanes 16]
+Server and clients share one process (asyncio); the clients verify nothing, they count and time."""
+import argparse, asyncio, importlib, json, os, random, statistics, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+shp = importlib.import_module("zkos-monorepo_amd")
+circuits = importlib.import_module("zkos-monorepo_amd.circuits")
+S = importlib.import_module("zkos-monorepo_amd.serve")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clients", type=int, default=48)
+    ap.add_argument("--requests", type=int, default=20)
+    ap.add_argument("--lanes", type=int, default=16)
+    a = ap.parse_args()
+    ctx = shp.Context(0)
+    plan, lay = circuits.build_withdraw_plan()
+    params = shp.Params.synthetic(ctx, 13, 0xDEADBEEF12345678)
+    pk = shp.ProvingKey(ctx, params, plan)
+    pool = shp.Pool(pk, a.lanes)
+    rnd = random.Random(5)
+    le = lambda x: list(int(x).to_bytes(32, "little"))
+    h = lay.height
+    reqs = []
+    for _ in range(8):
+        wit = circuits.withdraw_witness_inputs(lay, shp.poseidon2_hash_host, rnd)
+        inputs = {"id": le(wit[lay.ID]), "nullifier_old": le(wit[lay.NULLIFIER_OLD]), "account_balance_old": le(wit[lay.BALANCE_OLD]),
+                  "token_address": le(wit[lay.TOKEN]), "path": [b for x in wit[4:4 + 7 * h] for b in le(x)], "value": le(wit[lay.VALUE]),
+                  "nullifier_new": le(wit[lay.NULLIFIER_NEW]), "commitment": le(wit[lay.COMMITMENT]), "mac_salt": le(wit[lay.MAC_SALT])}
+        payload = {"circuit_type": "Withdraw", "user_public_key": [], "circuit_inputs": list(json.dumps(inputs).encode())}
+        reqs.append(S.encode_frame({"GenerateProof": {"payload": list(json.dumps(payload).encode())}}))
+    lat = []
+
+    async def client(i, port):
+        reader, writer = await asyncio.open_connection("127.0.0.1", port)
+        for j in range(a.requests):
+            t0 = time.perf_counter()
+            writer.write(reqs[(i + j) % len(reqs)])
+            await writer.drain()
+            resp = await S.read_frame(reader)
+            assert "EncryptedProof" in resp, resp
+            lat.append(time.perf_counter() - t0)
+        writer.close()
+
+    async def run():
+        loop = asyncio.get_running_loop()
+        from concurrent.futures import ThreadPoolExecutor
+        loop.set_default_executor(ThreadPoolExecutor(max_workers=max(32, 2 * a.lanes)))
+        srv = await S.Server(S.PoolBackend(pool, h)).serve(port=0)
+        port = srv.sockets[0].getsockname()[1]
+        async with srv:
+            await asyncio.gather(*[client(i, port) for i in range(min(4, a.clients))])     # warm-up
+            lat.clear()
+            t0 = time.perf_counter()
+            await asyncio.gather(*[client(i, port) for i in range(a.clients)])
+            return time.perf_counter() - t0
+
+    el = asyncio.run(run())
+    lat.sort()
+    n = len(lat)
+    print(json.dumps({"serve_path": "TCP + TEE JSON framing + shp_pool", "clients": a.clients, "lanes": a.lanes, "requests": n,
+                      "request_bytes": len(reqs[0]), "proofs_per_s": n / el, "latency_ms_p50": 1e3 * lat[n // 2],
+                      "latency_ms_p99": 1e3 * lat[min(n - 1, int(n * 0.99))], "latency_ms_mean": 1e3 * statistics.mean(lat)}))
+    pool.close(); pk.close(); params.close()
+
+
+if __name__ == "__main__":
+    main()

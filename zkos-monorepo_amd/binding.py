@@ -520,3 +520,30 @@ class Pool:
         if self.h:
             lib().shp_pool_destroy(self.h)
             self.h = C.c_void_p()
+
+
+# ---- TEE wire protocol, native front door (csrc/wire.hip) ---------------------------------------------
+TEE_PING, TEE_PUBLIC_KEY, TEE_GENERATE_PROOF = 0, 1, 2
+TEE_CIRCUITS = ("NewAccount", "Deposit", "Withdraw")                     # CircuitType, protocol.rs:62-68
+
+
+def tee_decode_request(body: bytes, height: int):
+    """one frame body -> (kind, circuit name or None, witness bytes or None); ShpError(SHP_ERR_FORMAT) on a bad frame"""
+    kind, circuit, n = C.c_int32(), C.c_int32(), C.c_size_t()
+    cap = 8 * 32 + 32 * 7 * height
+    wit = C.create_string_buffer(cap)
+    _check(lib().shp_tee_decode_request(C.c_char_p(body), C.c_size_t(len(body)), C.c_uint32(height), C.byref(kind),
+                                        C.byref(circuit), wit, C.c_size_t(cap), C.byref(n)))
+    if kind.value != TEE_GENERATE_PROOF:
+        return kind.value, None, None
+    return kind.value, TEE_CIRCUITS[circuit.value], wit.raw[:32 * n.value]
+
+
+def tee_encode_proof_response(circuit: str, proof: bytes, instances) -> bytes:
+    """Response::EncryptedProof as one JSON frame body (instances: ints or 32-byte LE blobs)"""
+    ins = b"".join(x if isinstance(x, (bytes, bytearray)) else int(x).to_bytes(32, "little") for x in instances)
+    cap = 256 + 2 * len(proof) + 6 * len(ins) * 2
+    out, n = C.create_string_buffer(cap), C.c_size_t()
+    _check(lib().shp_tee_encode_proof_response(C.c_int32(TEE_CIRCUITS.index(circuit)), C.c_char_p(proof), C.c_size_t(len(proof)),
+                                               C.c_char_p(ins), C.c_size_t(len(ins) // 32), out, C.c_size_t(cap), C.byref(n)))
+    return out.raw[:n.value]

@@ -1,0 +1,255 @@
+// TEE wire protocol, native side: decode of a GenerateProof request frame and encode of the EncryptedProof response.
+//
+// The reference's messages are serde_json values whose byte vectors are JSON arrays of numbers, nested three deep
+// (Request.payload -> Payload.circuit_inputs -> *ProveInputsBytes fields: /root/reference/tee/crates/
+// shielder-prover-common/src/protocol.rs:14-68, tee/crates/shielder-prover-tee/src/circuits/withdraw.rs:64-76,
+// deposit.rs:61-72): a Withdraw request is a 170 KB frame for 3 KB of witness.  Decoding it with a general JSON library
+// on the serving thread costs more than the proof costs the GPU (Python: ~4 ms per request against 0.8 ms per proof),
+// so the front door is a single-pass parser for exactly this schema: no DOM, byte arrays straight into buffers.
+// Host code only; the .hip suffix is for the build.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "field.cuh"
+
+namespace {
+
+struct Cur {
+    const uint8_t* p;
+    const uint8_t* e;
+};
+
+[[noreturn]] void bad(const char* what) { throw shp::Error(SHP_ERR_FORMAT, std::string("tee request: ") + what); }
+
+void ws(Cur& c) {
+    while (c.p < c.e && (*c.p == ' ' || *c.p == '\n' || *c.p == '\r' || *c.p == '\t')) c.p++;
+}
+bool peek(Cur& c, char ch) {
+    ws(c);
+    return c.p < c.e && *c.p == (uint8_t)ch;
+}
+void expect(Cur& c, char ch) {
+    if (!peek(c, ch)) bad("unexpected character");
+    c.p++;
+}
+std::string str(Cur& c) {
+    expect(c, '"');
+    std::string s;
+    while (c.p < c.e && *c.p != '"') {
+        if (*c.p == '\\') {                                  // field names and enum tags never need escapes
+            if (c.p + 1 >= c.e) bad("truncated escape");
+            const char x = (char)c.p[1];
+            if (x == 'u') bad("unicode escapes are not part of this protocol");
+            s.push_back(x == 'n' ? '\n' : x == 't' ? '\t' : x == 'r' ? '\r' : x == 'b' ? '\b' : x == 'f' ? '\f' : x);
+            c.p += 2;
+        } else {
+            s.push_back((char)*c.p++);
+        }
+    }
+    if (c.p >= c.e) bad("unterminated string");
+    c.p++;
+    return s;
+}
+// [n, n, ...] with 0 <= n <= 255
+void bytes_array(Cur& c, std::vector<uint8_t>& out) {
+    out.clear();
+    expect(c, '[');
+    if (peek(c, ']')) { c.p++; return; }
+    for (;;) {
+        ws(c);
+        if (c.p >= c.e || *c.p < '0' || *c.p > '9') bad("byte array: expected a number");
+        uint32_t v = 0;
+        while (c.p < c.e && *c.p >= '0' && *c.p <= '9') {
+            v = v * 10 + (*c.p++ - '0');
+            if (v > 255) bad("byte array: value above 255");
+        }
+        out.push_back((uint8_t)v);
+        ws(c);
+        if (c.p < c.e && *c.p == ',') { c.p++; continue; }
+        expect(c, ']');
+        return;
+    }
+}
+void skip(Cur& c) {                                          // any JSON value
+    ws(c);
+    if (c.p >= c.e) bad("truncated value");
+    if (*c.p == '"') { (void)str(c); return; }
+    if (*c.p == '[' || *c.p == '{') {
+        const char open = (char)*c.p, close = open == '[' ? ']' : '}';
+        c.p++;
+        if (peek(c, close)) { c.p++; return; }
+        for (;;) {
+            if (open == '{') { (void)str(c); expect(c, ':'); }
+            skip(c);
+            ws(c);
+            if (c.p < c.e && *c.p == ',') { c.p++; continue; }
+            expect(c, close);
+            return;
+        }
+    }
+    while (c.p < c.e && *c.p != ',' && *c.p != ']' && *c.p != '}' && *c.p != ' ' && *c.p != '\n') c.p++;   // number / literal
+}
+template <class F>
+void object(Cur& c, F on_key) {                               // on_key(key, cur) consumes the value
+    expect(c, '{');
+    if (peek(c, '}')) { c.p++; return; }
+    for (;;) {
+        std::string k = str(c);
+        expect(c, ':');
+        on_key(k, c);
+        ws(c);
+        if (c.p < c.e && *c.p == ',') { c.p++; continue; }
+        expect(c, '}');
+        return;
+    }
+}
+void end_of_input(Cur& c) {
+    ws(c);
+    if (c.p != c.e) bad("trailing bytes");
+}
+
+// argument order of WithdrawCircuit::prove / DepositCircuit::prove (crates/shielder_bindings/src/circuits/
+// withdraw.rs:88-114, deposit.rs:88-114) = field order of the TEE's *ProveInputsBytes
+const char* const WITHDRAW_FIELDS[9] = {"id", "nullifier_old", "account_balance_old", "token_address", "path", "value",
+                                        "nullifier_new", "commitment", "mac_salt"};
+const char* const DEPOSIT_FIELDS[9] = {"id", "nullifier_old", "account_balance_old", "token_address", "path", "value",
+                                       "commitment", "nullifier_new", "mac_salt"};
+// *PubInputsBytes field order (tee/.../circuits/withdraw.rs:12-23, deposit.rs:13-22)
+const char* const WITHDRAW_PUB[8] = {"merkle_root", "h_nullifier_old", "h_note_new", "withdrawal_value", "token_address",
+                                     "commitment", "mac_salt", "mac_commitment"};
+const char* const DEPOSIT_PUB[8] = {"merkle_root", "h_nullifier_old", "h_note_new", "value", "commitment", "token_address",
+                                    "mac_salt", "mac_commitment"};
+
+void b64(const uint8_t* d, size_t n, std::string& out) {
+    static const char T[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    size_t i = 0;
+    for (; i + 2 < n; i += 3) {
+        uint32_t v = (d[i] << 16) | (d[i + 1] << 8) | d[i + 2];
+        out.push_back(T[v >> 18]); out.push_back(T[(v >> 12) & 63]); out.push_back(T[(v >> 6) & 63]); out.push_back(T[v & 63]);
+    }
+    if (i + 1 == n) {
+        uint32_t v = d[i] << 16;
+        out.push_back(T[v >> 18]); out.push_back(T[(v >> 12) & 63]); out += "==";
+    } else if (i + 2 == n) {
+        uint32_t v = (d[i] << 16) | (d[i + 1] << 8);
+        out.push_back(T[v >> 18]); out.push_back(T[(v >> 12) & 63]); out.push_back(T[(v >> 6) & 63]); out.push_back('=');
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t shp_tee_decode_request(const uint8_t* json, size_t len, uint32_t height, int32_t* kind, int32_t* circuit,
+                               uint8_t* witness_le32, size_t witness_cap, size_t* n_inputs) {
+    return shp::guarded([&] {
+        SHP_REQUIRE(json && kind && circuit && n_inputs, SHP_ERR_INVALID_ARG, "tee_decode_request: null argument");
+        *kind = -1; *circuit = -1; *n_inputs = 0;
+        Cur c{json, json + len};
+        ws(c);
+        if (c.p < c.e && *c.p == '"') {                       // unit variants are bare strings (serde external tagging)
+            const std::string v = str(c);
+            end_of_input(c);
+            if (v == "Ping") *kind = SHP_TEE_PING;
+            else if (v == "TeePublicKey") *kind = SHP_TEE_PUBLIC_KEY;
+            else bad("unknown request");
+            return;
+        }
+        std::vector<uint8_t> payload, inner, field;
+        bool have_payload = false;
+        object(c, [&](const std::string& k, Cur& cc) {
+            if (k != "GenerateProof") bad("unknown request");
+            object(cc, [&](const std::string& k2, Cur& c2) {
+                if (k2 == "payload") { bytes_array(c2, payload); have_payload = true; }
+                else skip(c2);
+            });
+        });
+        end_of_input(c);
+        if (!have_payload) bad("GenerateProof without payload");
+        *kind = SHP_TEE_GENERATE_PROOF;
+        // Payload { circuit_type, user_public_key, circuit_inputs }
+        std::string ctype;
+        bool have_inputs = false, have_key = false;
+        Cur pc{payload.data(), payload.data() + payload.size()};
+        object(pc, [&](const std::string& k, Cur& cc) {
+            if (k == "circuit_type") ctype = str(cc);
+            else if (k == "user_public_key") { bytes_array(cc, field); have_key = true; }
+            else if (k == "circuit_inputs") { bytes_array(cc, inner); have_inputs = true; }
+            else skip(cc);
+        });
+        end_of_input(pc);
+        if (!have_inputs || !have_key) bad("payload: missing fields");
+        if (ctype == "Withdraw") *circuit = SHP_TEE_WITHDRAW;
+        else if (ctype == "Deposit") *circuit = SHP_TEE_DEPOSIT;
+        else if (ctype == "NewAccount") *circuit = SHP_TEE_NEW_ACCOUNT;
+        else bad("payload: bad circuit_type");
+        if (*circuit == SHP_TEE_NEW_ACCOUNT) bad("circuit NewAccount: no proving key loaded");
+        const char* const* fields = *circuit == SHP_TEE_WITHDRAW ? WITHDRAW_FIELDS : DEPOSIT_FIELDS;
+        // witness layout: 4 scalars | path | 4 scalars, 32 bytes each
+        const size_t path_bytes = (size_t)32 * 7 * height, total = 8 * 32 + path_bytes;
+        SHP_REQUIRE(witness_le32 && witness_cap >= total, SHP_ERR_INVALID_ARG, "tee_decode_request: witness buffer too small");
+        size_t offset[9];
+        {
+            size_t off = 0;
+            for (int f = 0; f < 9; f++) { offset[f] = off; off += f == 4 ? path_bytes : 32; }
+        }
+        bool seen[9] = {false};
+        Cur ic{inner.data(), inner.data() + inner.size()};
+        object(ic, [&](const std::string& k, Cur& cc) {
+            int f = -1;
+            for (int i = 0; i < 9; i++)
+                if (k == fields[i]) f = i;
+            if (f < 0) { skip(cc); return; }
+            bytes_array(cc, field);
+            const size_t want = f == 4 ? path_bytes : 32;
+            if (field.size() != want) bad("circuit_inputs: field of the wrong length");
+            for (size_t o = 0; o < want; o += 32) {          // vec_to_f panics on a non-canonical element (utils.rs:33)
+                shp::Fr raw;
+                memcpy(raw.l, field.data() + o, 32);
+                if (raw.geq_p()) bad("circuit_inputs: not a canonical field element");
+            }
+            memcpy(witness_le32 + offset[f], field.data(), want);
+            seen[f] = true;
+        });
+        end_of_input(ic);
+        for (int f = 0; f < 9; f++)
+            if (!seen[f]) bad("circuit_inputs: missing field");
+        *n_inputs = total / 32;
+    });
+}
+
+int32_t shp_tee_encode_proof_response(int32_t circuit, const uint8_t* proof, size_t proof_len, const uint8_t* instances_le32,
+                                      size_t n_instances, uint8_t* out, size_t cap, size_t* out_len) {
+    return shp::guarded([&] {
+        SHP_REQUIRE(proof && instances_le32 && out_len, SHP_ERR_INVALID_ARG, "tee_encode_proof_response: null argument");
+        SHP_REQUIRE((circuit == SHP_TEE_WITHDRAW || circuit == SHP_TEE_DEPOSIT) && n_instances == 8, SHP_ERR_INVALID_ARG,
+                    "tee_encode_proof_response: unsupported circuit or instance count");
+        const char* const* names = circuit == SHP_TEE_WITHDRAW ? WITHDRAW_PUB : DEPOSIT_PUB;
+        std::string pub = "{";                               // serde_json::to_vec(&*PubInputsBytes) (server.rs:192)
+        for (size_t i = 0; i < n_instances; i++) {
+            if (i) pub.push_back(',');
+            pub.push_back('"');
+            pub += names[i];
+            pub += "\":[";
+            for (int b = 0; b < 32; b++) {
+                if (b) pub.push_back(',');
+                pub += std::to_string((unsigned)instances_le32[32 * i + b]);
+            }
+            pub.push_back(']');
+        }
+        pub.push_back('}');
+        std::string body = "{\"EncryptedProof\":{\"proof\":\"";
+        b64(proof, proof_len, body);
+        body += "\",\"pub_inputs\":\"";
+        b64((const uint8_t*)pub.data(), pub.size(), body);
+        body += "\"}}";
+        *out_len = body.size();
+        SHP_REQUIRE(out && cap >= body.size(), SHP_ERR_INVALID_ARG, "tee_encode_proof_response: buffer too small");
+        memcpy(out, body.data(), body.size());
+    });
+}
+
+}  // extern "C"

@@ -45,12 +45,16 @@ def encode_frame(obj) -> bytes:
     return struct.pack(">I", len(body)) + body
 
 
-async def read_frame(reader: asyncio.StreamReader):
+async def read_frame_raw(reader: asyncio.StreamReader) -> bytes:
     hdr = await reader.readexactly(4)
     (n,) = struct.unpack(">I", hdr)
     if n > 8 * 1024 * 1024:                                     # LengthDelimitedCodec max_frame_length default
         raise ProtocolError("frame too large")
-    return json.loads(await reader.readexactly(n))
+    return await reader.readexactly(n)
+
+
+async def read_frame(reader: asyncio.StreamReader):
+    return json.loads(await read_frame_raw(reader))
 
 
 # ---- message mapping ------------------------------------------------------------------------
@@ -111,6 +115,12 @@ class Server:
         self.backends = backend if isinstance(backend, dict) else {"Withdraw": backend}
         self.seed_source = seed_source          # the reference uses rand::thread_rng() (withdraw.rs:112)
         self.served = 0
+        try:                                    # the library's wire codec (absent only when the .so is not built)
+            from . import binding as _b
+            _b.lib()
+            self.native = _b
+        except Exception:
+            self.native = None
 
     async def handle_request(self, req, loop):
         if req == "Ping":
@@ -130,15 +140,36 @@ class Server:
             return {"EncryptedProof": {"proof": base64.b64encode(proof).decode(), "pub_inputs": base64.b64encode(pub).decode()}}
         raise ProtocolError("unknown request")
 
+    async def handle_frame(self, body: bytes, loop) -> bytes:
+        """one request frame -> one response frame.  Requests are decoded and proof responses encoded by the library
+        (shp_tee_decode_request / shp_tee_encode_proof_response, GIL released): a Withdraw request is 170 KB of nested
+        JSON number arrays, 4 ms of json.loads per request on the event-loop thread against 0.8 ms per proof on the GPU"""
+        heights = {b.n_height for b in self.backends.values()}
+        if self.native is None or len(heights) != 1:
+            return encode_frame(await self.handle_request(json.loads(body), loop))
+        try:
+            kind, ctype, wit = await loop.run_in_executor(None, self.native.tee_decode_request, body, heights.pop())
+        except self.native.ShpError as e:
+            raise ProtocolError(str(e))
+        if kind != self.native.TEE_GENERATE_PROOF:
+            return encode_frame(await self.handle_request("Ping" if kind == self.native.TEE_PING else "TeePublicKey", loop))
+        backend = self.backends.get(ctype)
+        if backend is None:
+            raise ProtocolError(f"circuit {ctype}: no proving key loaded")
+        proof, instances = await loop.run_in_executor(None, backend.prove, wit, self.seed_source(32))
+        self.served += 1
+        body_out = self.native.tee_encode_proof_response(ctype, proof, instances)
+        return struct.pack(">I", len(body_out)) + body_out
+
     async def handle_client(self, reader, writer):
         loop = asyncio.get_running_loop()
         try:
             while True:
                 try:
-                    req = await read_frame(reader)
+                    body = await read_frame_raw(reader)
                 except asyncio.IncompleteReadError:
                     break
-                writer.write(encode_frame(await self.handle_request(req, loop)))
+                writer.write(await self.handle_frame(body, loop))
                 await writer.drain()
         except (ProtocolError, ValueError) as e:      # the reference drops the connection on a protocol error
             print(f"[serve] protocol error: {e}", flush=True)
