@@ -282,6 +282,52 @@ def test_deposit_shaped_plan_proof_bytes(shp, oracle, gpu_ctx):
     pr.close(); pk.close(); params.close()
 
 
+def test_new_account_shaped_plan_proof_and_serve(shp, oracle, gpu_ctx):
+    """the NewAccount-shaped plan (NewAccountProverKnowledge argument order, the contract's 13 public inputs;
+    the ElGamal ciphertext replaced by documented Poseidon2 placeholders): proof bytes equal the oracle's, the public
+    inputs mean what the layout says, and a NewAccount request in the TEE wire format is served end to end"""
+    import asyncio, base64, json
+    from oracle import plonk as PL
+    C = importlib.import_module("zkos-monorepo_amd.circuits")
+    S = importlib.import_module("zkos-monorepo_amd.serve")
+    plan_bytes, lay = C.build_withdraw_plan(9, 0, 4, 8, kind="new_account")
+    osrs = oracle.srs_synthetic(9, TAU)
+    opk = PL.keygen(PL.Plan(plan_bytes), osrs)
+    params = shp.Params.synthetic(gpu_ctx, 9, TAU)
+    pk = shp.ProvingKey(gpu_ctx, params, plan_bytes)
+    assert (pk.n_inputs, pk.n_instances) == (9, 13)
+    wit = C.new_account_witness_inputs(lay, random.Random(6), 2**31 + 9)
+    pr = shp.Prover(pk)
+    proof, inst = pr.prove(wit, bytes([8]) * 32)
+    assert (proof, inst) == PL.prove(opk, osrs, wit, bytes([8]) * 32)
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    idv, nul, dep, com, tok, salt, msalt, arx, ary = wit
+    c1x, c1y = H([salt, arx]), H([salt, ary])
+    assert inst == [H([idv, nul, dep, tok]), H([idv]), dep, com, tok, arx, ary, c1x, c1y, H([idv, c1x]), H([idv, c1y]), msalt,
+                    H([msalt, idv])]
+    assert PL.verify(opk, proof, inst, tau=TAU) and pk.verify(proof, inst)
+    # over the wire
+    le = lambda x: list(int(x).to_bytes(32, "little"))
+    inputs = {f: le(v) for f, v in zip(S.NEW_ACCOUNT_INPUT_FIELDS, wit)}
+    payload = {"circuit_type": "NewAccount", "user_public_key": [], "circuit_inputs": list(json.dumps(inputs).encode())}
+    req = {"GenerateProof": {"payload": list(json.dumps(payload).encode())}}
+    pool = shp.Pool(pk, 2)
+
+    async def run():
+        srv = await S.Server({"NewAccount": S.PoolBackend(pool, 0)}).serve(port=0)
+        port = srv.sockets[0].getsockname()[1]
+        async with srv:
+            return await S.request("127.0.0.1", port, req)
+
+    r = asyncio.run(run())
+    proof2 = base64.b64decode(r["EncryptedProof"]["proof"])
+    pub = json.loads(base64.b64decode(r["EncryptedProof"]["pub_inputs"]))
+    assert list(pub) == list(S.NEW_ACCOUNT_PUB_FIELDS)
+    assert [int.from_bytes(bytes(pub[f]), "little") for f in S.NEW_ACCOUNT_PUB_FIELDS] == inst
+    assert pk.verify(proof2, inst)
+    pool.close(); pr.close(); pk.close(); params.close()
+
+
 @pytest.mark.parametrize("small", [True, False])
 def test_witness_schedule_threads_give_identical_proofs(shp, oracle, gpu_ctx, small):
     """the witness program cut into parallel tasks (1, 2, 4, 7 host threads) yields the same proof bytes as

@@ -81,3 +81,32 @@ def test_oracle_prover_small_roundtrip(oracle):
     assert p1 == p2 and p1 != p3 and i1 == list(inst0)[:len(i1)]
     assert PL.verify(opk, p1, i1, tau=TAU) and PL.verify(opk, p3, i1, tau=TAU)
     assert not PL.verify(opk, p1[:-1] + bytes([p1[-1] ^ 1]), i1, tau=TAU)
+
+
+def test_new_account_shaped_plan(oracle):
+    """the NewAccount-shaped stand-in (circuits/withdraw.py::build_new_account_plan): the generated witness satisfies the
+    generated circuit, the 13 public inputs are the documented functions of the 9 arguments, prove -> verify"""
+    import importlib, random
+    PL = importlib.import_module("oracle.plonk")
+    C = importlib.import_module("zkos-monorepo_amd.circuits")
+    plan_bytes, lay = C.build_withdraw_plan(9, 0, 4, 8, kind="new_account")
+    plan = PL.Plan(plan_bytes)
+    wit = C.new_account_witness_inputs(lay, random.Random(4), 2**31 + 77)
+    grid, inst = PL.synthesize(plan, wit)
+    assert PL.mock_check(plan, grid, inst) == []
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    idv, nul, dep, com, tok, salt, msalt, arx, ary = wit
+    c1x, c1y = H([salt, arx]), H([salt, ary])
+    assert list(inst) == [H([idv, nul, dep, tok]), H([idv]), dep, com, tok, arx, ary, c1x, c1y, H([idv, c1x]), H([idv, c1y]),
+                          msalt, H([msalt, idv])]
+    assert len(lay.INSTANCES) == 13 and lay.n_inputs == 9
+    srs = oracle.srs_synthetic(9, 987654321)
+    pk = PL.keygen(plan, srs)
+    proof, ins = PL.prove(pk, srs, wit, bytes([1]) * 32)
+    assert PL.verify(pk, proof, ins, tau=987654321)
+    bad = list(ins); bad[2] += 1                                  # a different deposit is not what was proved
+    assert not PL.verify(pk, proof, bad, tau=987654321)
+    # an initial deposit outside the range check does not satisfy the circuit
+    big = list(wit); big[2] = 1 << 40
+    g2, i2 = PL.synthesize(plan, big)
+    assert PL.mock_check(plan, g2, i2) != []

@@ -119,6 +119,13 @@ def test_native_wire_codec_matches_the_python_mirror():
             kind, c, wit = B.tee_decode_request(body, height)
             assert (kind, c) == (B.TEE_GENERATE_PROOF, ctype)
             assert wit == S.withdraw_witness_bytes(inputs, height, fields)
+    # NewAccount: nine scalar arguments, no path (height is irrelevant)
+    na = {f: le(1000 + i) for i, f in enumerate(S.NEW_ACCOUNT_INPUT_FIELDS)}
+    kind, c, wit = B.tee_decode_request(json.dumps(make_request(na, "NewAccount")).encode(), 13)
+    assert (kind, c) == (B.TEE_GENERATE_PROOF, "NewAccount")
+    assert wit == S.withdraw_witness_bytes(na, 13, S.NEW_ACCOUNT_INPUT_FIELDS) and len(wit) == 9 * 32
+    d = json.loads(B.tee_encode_proof_response("NewAccount", b"\x01\x02", list(range(13))))
+    assert base64.b64decode(d["EncryptedProof"]["pub_inputs"]) == S.withdraw_pub_inputs_json(list(range(13)), S.NEW_ACCOUNT_PUB_FIELDS)
     # pretty-printed JSON and an extra field
     inputs = make_inputs(2)
     payload = {"circuit_type": "Withdraw", "extra": {"a": [1, "x", None]}, "user_public_key": [], "circuit_inputs":

@@ -530,7 +530,7 @@ TEE_CIRCUITS = ("NewAccount", "Deposit", "Withdraw")                     # Circu
 def tee_decode_request(body: bytes, height: int):
     """one frame body -> (kind, circuit name or None, witness bytes or None); ShpError(SHP_ERR_FORMAT) on a bad frame"""
     kind, circuit, n = C.c_int32(), C.c_int32(), C.c_size_t()
-    cap = 8 * 32 + 32 * 7 * height
+    cap = 16 * 32 + 32 * 7 * height                      # up to 16 scalar arguments + the Merkle path
     wit = C.create_string_buffer(cap)
     _check(lib().shp_tee_decode_request(C.c_char_p(body), C.c_size_t(len(body)), C.c_uint32(height), C.byref(kind),
                                         C.byref(circuit), wit, C.c_size_t(cap), C.byref(n)))

@@ -54,6 +54,20 @@ class WithdrawLayout:
     def MAC_SALT(self): return 7 + 7 * self.height
 
 
+class NewAccountLayout:
+    """NewAccount-shaped stand-in: the 9 arguments of NewAccountCircuit::prove in order
+    (/root/reference/crates/shielder_bindings/src/circuits/new_account.rs:108-140) and the 13 public inputs in the
+    order the contract assembles them (/root/reference/contracts/Shielder.sol:345-370)"""
+    INSTANCES = ["HashedNote", "Prenullifier", "InitialDeposit", "Commitment", "TokenAddress",
+                 "AnonymityRevokerPublicKeyX", "AnonymityRevokerPublicKeyY", "EncryptedKeyCiphertext1X",
+                 "EncryptedKeyCiphertext1Y", "EncryptedKeyCiphertext2X", "EncryptedKeyCiphertext2Y", "MacSalt",
+                 "MacCommitment"]
+    ID, NULLIFIER, INITIAL_DEPOSIT, COMMITMENT, TOKEN, ENCRYPTION_SALT, MAC_SALT, AR_X, AR_Y = range(9)
+    kind = "new_account"
+    height = 0
+    n_inputs = 9
+
+
 def _m4(a, b, c, d):
     ab, cd = a + b, c + d
     t2 = (b + b) + cd
@@ -77,11 +91,24 @@ def build_deposit_plan(k=13, height=13, range_bits=12, range_chunks=10):
     return build_withdraw_plan(k, height, range_bits, range_chunks, kind="deposit")
 
 
+def build_new_account_plan(k=12, range_bits=11, range_chunks=11):
+    """NewAccount-shaped stand-in on the same engine (same columns, gates and lookup as the withdraw plan):
+      prenullifier  = H(id)                                              -> instance 1
+      note          = H(id, nullifier, initial_deposit, token)           -> instance 0
+      initial_deposit range-checked, -> instance 2;  commitment, token, AR key x / y -> instances 3..6
+      mac_commitment = H(mac_salt, id)                                   -> instances 11, 12
+    DEVIATION: the reference encrypts a symmetric key derived from id to the anonymity revoker with in-circuit Grumpkin
+    ElGamal (instances 7..10 are the two ciphertext points); that gadget lives in the un-vendored zkOS-circuits crate.
+    Here the four coordinates are Poseidon2 placeholders, c1 = (H(salt, ar_x), H(salt, ar_y)), c2 = (H(id, c1x),
+    H(id, c1y)): the argument vector, the 13 public inputs and their order are the reference's, the relation is not."""
+    return build_withdraw_plan(k, 0, range_bits, range_chunks, kind="new_account")
+
+
 def build_withdraw_plan(k=13, height=13, range_bits=12, range_chunks=10, kind="withdraw"):
     b = PlanBuilder(k)
-    lay = WithdrawLayout(height, kind)
+    lay = NewAccountLayout() if kind == "new_account" else WithdrawLayout(height, kind)
     b.n_winputs = lay.n_inputs
-    b.num_instance = 8
+    b.num_instance = len(lay.INSTANCES)
     s = [b.advice_column() for _ in range(8)]
     wcol, zcol = b.advice_column(), b.advice_column()
     rc = [b.fixed_column() for _ in range(8)]
@@ -208,6 +235,45 @@ def build_withdraw_plan(k=13, height=13, range_bits=12, range_chunks=10, kind="w
         b.instance_map.append(cell)
         b.copy(A(*cell), (COL_INSTANCE, 0, idx))
 
+    def range_check(cell):
+        r0 = state["row"]
+        state["row"] += range_chunks + 1
+        b.w(W_COPY, (zcol, r0), cell)
+        b.copy(A(zcol, r0), A(*cell))
+        for i in range(range_chunks):
+            b.fix(q_rsum, r0 + i, 1)
+            b.fix(q_range, r0 + i, 1)
+            b.w(W_BITS, (wcol, r0 + i), (zcol, r0 + i), imm=range_bits)
+            b.w(W_SHR, (zcol, r0 + i + 1), (zcol, r0 + i), imm=range_bits)
+        b.copy(A(zcol, r0 + range_chunks), const_cell(0))
+
+    def finish():
+        usable = b.n - (b.blinding_factors() + 1)
+        assert state["row"] <= usable and (1 << range_bits) <= usable, "circuit does not fit 2^k rows"
+        return b.build(), lay
+
+    if kind == "new_account":
+        pre, r_pre = poseidon([("in", lay.ID)])
+        id_cell = (s[0], r_pre)
+        note, r_note = poseidon([("cell", id_cell), ("in", lay.NULLIFIER), ("in", lay.INITIAL_DEPOSIT), ("in", lay.TOKEN)])
+        deposit_cell, token_cell = (s[2], r_note), (s[3], r_note)
+        range_check(deposit_cell)
+        c1x, r1 = poseidon([("in", lay.ENCRYPTION_SALT), ("in", lay.AR_X)])
+        salt_cell, arx_cell = (s[0], r1), (s[1], r1)
+        c1y, r2 = poseidon([("cell", salt_cell), ("in", lay.AR_Y)])
+        ary_cell = (s[1], r2)
+        c2x, _ = poseidon([("cell", id_cell), ("cell", c1x)])
+        c2y, _ = poseidon([("cell", id_cell), ("cell", c1y)])
+        mac, r_mac = poseidon([("in", lay.MAC_SALT), ("cell", id_cell)])
+        mac_salt_cell = (s[0], r_mac)
+        fr = state["row"]                      # a row no selector touches: the commitment is a plain public input
+        state["row"] += 1
+        b.w(W_INPUT, (s[3], fr), imm=lay.COMMITMENT)
+        for idx, cell in enumerate([note, pre, deposit_cell, (s[3], fr), token_cell, arx_cell, ary_cell, c1x, c1y, c2x, c2y,
+                                    mac_salt_cell, mac]):
+            expose(cell, idx)
+        return finish()
+
     # ---- synthesis
     h_null, r_null = poseidon([("in", lay.NULLIFIER_OLD)])
     note_old, r_note = poseidon([("in", lay.ID), ("cell", (s[0], r_null)), ("in", lay.BALANCE_OLD), ("in", lay.TOKEN)])
@@ -244,18 +310,6 @@ def build_withdraw_plan(k=13, height=13, range_bits=12, range_chunks=10, kind="w
         b.w(W_ADD, (s[2], ar), (s[0], ar), (s[1], ar))
         bal_new_cell, value_cell = (s[2], ar), (s[1], ar)
 
-    def range_check(cell):
-        r0 = state["row"]
-        state["row"] += range_chunks + 1
-        b.w(W_COPY, (zcol, r0), cell)
-        b.copy(A(zcol, r0), A(*cell))
-        for i in range(range_chunks):
-            b.fix(q_rsum, r0 + i, 1)
-            b.fix(q_range, r0 + i, 1)
-            b.w(W_BITS, (wcol, r0 + i), (zcol, r0 + i), imm=range_bits)
-            b.w(W_SHR, (zcol, r0 + i + 1), (zcol, r0 + i), imm=range_bits)
-        b.copy(A(zcol, r0 + range_chunks), const_cell(0))
-
     range_check(bal_new_cell)
     range_check(value_cell)
     note_new, r_nn = poseidon([("cell", id_cell), ("in", lay.NULLIFIER_NEW), ("cell", bal_new_cell), ("cell", token_cell)])
@@ -278,9 +332,15 @@ def build_withdraw_plan(k=13, height=13, range_bits=12, range_chunks=10, kind="w
         expose(token_cell, 5)
     expose(mac_salt_cell, 6)
     expose(mac, 7)
-    usable = b.n - (b.blinding_factors() + 1)
-    assert state["row"] <= usable and (1 << range_bits) <= usable, "circuit does not fit 2^k rows"
-    return b.build(), lay
+    return finish()
+
+
+def new_account_witness_inputs(lay, rnd, initial_deposit=10**18):
+    """a witness input vector of the NewAccount-shaped plan (canonical ints); nothing to keep consistent: every
+    public input is computed by the witness program"""
+    from .builder import R_MOD as R
+    return [rnd.randrange(R), rnd.randrange(R), initial_deposit, rnd.randrange(R), rnd.randrange(1 << 160), rnd.randrange(R),
+            rnd.randrange(R), rnd.randrange(R), rnd.randrange(R)]
 
 
 def withdraw_witness_inputs(lay, hash_fn, rnd, balance_old=10**18, value=10**17):

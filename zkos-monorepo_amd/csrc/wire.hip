@@ -122,6 +122,25 @@ const char* const WITHDRAW_PUB[8] = {"merkle_root", "h_nullifier_old", "h_note_n
                                      "commitment", "mac_salt", "mac_commitment"};
 const char* const DEPOSIT_PUB[8] = {"merkle_root", "h_nullifier_old", "h_note_new", "value", "commitment", "token_address",
                                     "mac_salt", "mac_commitment"};
+// NewAccountProveInputsBytes / NewAccountPubInputsBytes (tee/.../circuits/new_account.rs:86-97, 13-28): no Merkle path
+const char* const NEW_ACCOUNT_FIELDS[9] = {"id", "nullifier", "initial_deposit", "commitment", "token_address", "encryption_salt",
+                                           "mac_salt", "anonymity_revoker_public_key_x", "anonymity_revoker_public_key_y"};
+const char* const NEW_ACCOUNT_PUB[13] = {"hashed_note", "prenullifier", "initial_deposit", "commitment", "token_address",
+                                         "anonymity_revoker_public_key_x", "anonymity_revoker_public_key_y",
+                                         "sym_key_encryption_1_x", "sym_key_encryption_1_y", "sym_key_encryption_2_x",
+                                         "sym_key_encryption_2_y", "mac_salt", "mac_commitment"};
+
+struct CircuitShape {
+    const char* const* fields;
+    int n_fields, path_index;          // path_index < 0: no path argument
+    const char* const* pub;
+    int n_pub;
+};
+const CircuitShape& shape_of(int32_t circuit) {
+    static const CircuitShape W{WITHDRAW_FIELDS, 9, 4, WITHDRAW_PUB, 8}, D{DEPOSIT_FIELDS, 9, 4, DEPOSIT_PUB, 8},
+        N{NEW_ACCOUNT_FIELDS, 9, -1, NEW_ACCOUNT_PUB, 13};
+    return circuit == SHP_TEE_WITHDRAW ? W : circuit == SHP_TEE_DEPOSIT ? D : N;
+}
 
 void b64(const uint8_t* d, size_t n, std::string& out) {
     static const char T[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
@@ -186,25 +205,21 @@ int32_t shp_tee_decode_request(const uint8_t* json, size_t len, uint32_t height,
         else if (ctype == "Deposit") *circuit = SHP_TEE_DEPOSIT;
         else if (ctype == "NewAccount") *circuit = SHP_TEE_NEW_ACCOUNT;
         else bad("payload: bad circuit_type");
-        if (*circuit == SHP_TEE_NEW_ACCOUNT) bad("circuit NewAccount: no proving key loaded");
-        const char* const* fields = *circuit == SHP_TEE_WITHDRAW ? WITHDRAW_FIELDS : DEPOSIT_FIELDS;
-        // witness layout: 4 scalars | path | 4 scalars, 32 bytes each
-        const size_t path_bytes = (size_t)32 * 7 * height, total = 8 * 32 + path_bytes;
+        const CircuitShape& sh = shape_of(*circuit);
+        // witness layout: the circuit's prove() arguments in order, 32 bytes each, the path height x 7 x 32
+        const size_t path_bytes = (size_t)32 * 7 * height;
+        size_t offset[16], total = 0;
+        for (int f = 0; f < sh.n_fields; f++) { offset[f] = total; total += f == sh.path_index ? path_bytes : 32; }
         SHP_REQUIRE(witness_le32 && witness_cap >= total, SHP_ERR_INVALID_ARG, "tee_decode_request: witness buffer too small");
-        size_t offset[9];
-        {
-            size_t off = 0;
-            for (int f = 0; f < 9; f++) { offset[f] = off; off += f == 4 ? path_bytes : 32; }
-        }
-        bool seen[9] = {false};
+        bool seen[16] = {false};
         Cur ic{inner.data(), inner.data() + inner.size()};
         object(ic, [&](const std::string& k, Cur& cc) {
             int f = -1;
-            for (int i = 0; i < 9; i++)
-                if (k == fields[i]) f = i;
+            for (int i = 0; i < sh.n_fields; i++)
+                if (k == sh.fields[i]) f = i;
             if (f < 0) { skip(cc); return; }
             bytes_array(cc, field);
-            const size_t want = f == 4 ? path_bytes : 32;
+            const size_t want = f == sh.path_index ? path_bytes : 32;
             if (field.size() != want) bad("circuit_inputs: field of the wrong length");
             for (size_t o = 0; o < want; o += 32) {          // vec_to_f panics on a non-canonical element (utils.rs:33)
                 shp::Fr raw;
@@ -215,7 +230,7 @@ int32_t shp_tee_decode_request(const uint8_t* json, size_t len, uint32_t height,
             seen[f] = true;
         });
         end_of_input(ic);
-        for (int f = 0; f < 9; f++)
+        for (int f = 0; f < sh.n_fields; f++)
             if (!seen[f]) bad("circuit_inputs: missing field");
         *n_inputs = total / 32;
     });
@@ -225,9 +240,9 @@ int32_t shp_tee_encode_proof_response(int32_t circuit, const uint8_t* proof, siz
                                       size_t n_instances, uint8_t* out, size_t cap, size_t* out_len) {
     return shp::guarded([&] {
         SHP_REQUIRE(proof && instances_le32 && out_len, SHP_ERR_INVALID_ARG, "tee_encode_proof_response: null argument");
-        SHP_REQUIRE((circuit == SHP_TEE_WITHDRAW || circuit == SHP_TEE_DEPOSIT) && n_instances == 8, SHP_ERR_INVALID_ARG,
-                    "tee_encode_proof_response: unsupported circuit or instance count");
-        const char* const* names = circuit == SHP_TEE_WITHDRAW ? WITHDRAW_PUB : DEPOSIT_PUB;
+        SHP_REQUIRE(circuit >= SHP_TEE_NEW_ACCOUNT && circuit <= SHP_TEE_WITHDRAW && (int)n_instances == shape_of(circuit).n_pub,
+                    SHP_ERR_INVALID_ARG, "tee_encode_proof_response: unknown circuit or wrong instance count");
+        const char* const* names = shape_of(circuit).pub;
         std::string pub = "{";                               // serde_json::to_vec(&*PubInputsBytes) (server.rs:192)
         for (size_t i = 0; i < n_instances; i++) {
             if (i) pub.push_back(',');

@@ -31,8 +31,14 @@ DEPOSIT_INPUT_FIELDS = ("id", "nullifier_old", "account_balance_old", "token_add
                         "commitment", "nullifier_new", "mac_salt")    # tee/.../circuits/deposit.rs:61-72
 DEPOSIT_PUB_FIELDS = ("merkle_root", "h_nullifier_old", "h_note_new", "value", "commitment", "token_address",
                       "mac_salt", "mac_commitment")                   # tee/.../circuits/deposit.rs:13-22
-INPUT_FIELDS = {"Withdraw": WITHDRAW_INPUT_FIELDS, "Deposit": DEPOSIT_INPUT_FIELDS}
-PUB_FIELDS = {"Withdraw": WITHDRAW_PUB_FIELDS, "Deposit": DEPOSIT_PUB_FIELDS}
+NEW_ACCOUNT_INPUT_FIELDS = ("id", "nullifier", "initial_deposit", "commitment", "token_address", "encryption_salt", "mac_salt",
+                            "anonymity_revoker_public_key_x", "anonymity_revoker_public_key_y")   # tee/.../new_account.rs:86-97
+NEW_ACCOUNT_PUB_FIELDS = ("hashed_note", "prenullifier", "initial_deposit", "commitment", "token_address",
+                          "anonymity_revoker_public_key_x", "anonymity_revoker_public_key_y", "sym_key_encryption_1_x",
+                          "sym_key_encryption_1_y", "sym_key_encryption_2_x", "sym_key_encryption_2_y", "mac_salt",
+                          "mac_commitment")                                                        # new_account.rs:13-28
+INPUT_FIELDS = {"Withdraw": WITHDRAW_INPUT_FIELDS, "Deposit": DEPOSIT_INPUT_FIELDS, "NewAccount": NEW_ACCOUNT_INPUT_FIELDS}
+PUB_FIELDS = {"Withdraw": WITHDRAW_PUB_FIELDS, "Deposit": DEPOSIT_PUB_FIELDS, "NewAccount": NEW_ACCOUNT_PUB_FIELDS}
 
 
 class ProtocolError(Exception):
