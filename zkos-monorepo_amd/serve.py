@@ -150,11 +150,12 @@ class Server:
         """one request frame -> one response frame.  Requests are decoded and proof responses encoded by the library
         (shp_tee_decode_request / shp_tee_encode_proof_response, GIL released): a Withdraw request is 170 KB of nested
         JSON number arrays, 4 ms of json.loads per request on the event-loop thread against 0.8 ms per proof on the GPU"""
-        heights = {b.n_height for b in self.backends.values()}
-        if self.native is None or len(heights) != 1:
+        heights = {b.n_height for b in self.backends.values() if b.n_height}      # NewAccount has no Merkle path
+        if self.native is None or len(heights) > 1:
             return encode_frame(await self.handle_request(json.loads(body), loop))
         try:
-            kind, ctype, wit = await loop.run_in_executor(None, self.native.tee_decode_request, body, heights.pop())
+            kind, ctype, wit = await loop.run_in_executor(None, self.native.tee_decode_request, body,
+                                                          heights.pop() if heights else 0)
         except self.native.ShpError as e:
             raise ProtocolError(str(e))
         if kind != self.native.TEE_GENERATE_PROOF:
@@ -224,9 +225,11 @@ def main():
     ctx = shp.Context(a.device)
     params = shp.Params.read_ptau(ctx, open(a.ptau, "rb").read()) if a.ptau else shp.Params.synthetic(ctx, 13, a.tau)
     backends = {}
-    for ctype, build in (("Withdraw", circuits.build_withdraw_plan), ("Deposit", circuits.build_deposit_plan)):
+    for ctype, build in (("Withdraw", circuits.build_withdraw_plan), ("Deposit", circuits.build_deposit_plan),
+                         ("NewAccount", circuits.build_new_account_plan)):
         plan, lay = build()
-        backends[ctype] = PoolBackend(shp.Pool(shp.ProvingKey(ctx, params, plan), a.lanes), lay.height)
+        _, _, pk = shp.ProvingKey.generate_keys_with_min_k(ctx, params, plan)      # NewAccount is a 2^12 circuit
+        backends[ctype] = PoolBackend(shp.Pool(pk, a.lanes), lay.height)
 
     async def run():
         srv = await Server(backends).serve(port=a.port)
