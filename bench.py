@@ -178,12 +178,16 @@ def main():
     # (the pool's 16 lanes run the witness program on one host thread each, a lone lane on four)
     lat_prover = shp.Prover(pk)
     lat_prover.prove_bytes(wits[0], bytes(32))
-    lat = []
+    lat_prover.profile(2)                        # the host phase clock of each proof, no events in the stream
+    lat, phase_samples = [], {}
     for i in range(a.latency_proofs):
         s = time.perf_counter()
-        lat_prover.prove_bytes(wits[i % len(wits)], bytes([i + 1]) * 32)
+        lat_prover.prove_bytes(wits[i % len(wits)], bytes([(i % 255) + 1]) * 32)
         lat.append(time.perf_counter() - s)
+        for name_, us_ in lat_prover.phases():
+            phase_samples.setdefault(name_, []).append(us_)
     lat.sort()
+    phase_us_p50 = {k_: sorted(v_)[len(v_) // 2] for k_, v_ in phase_samples.items()}
     lat_prover.close()
 
     assert all(lens_buf[i] == pk.proof_len for i in range(per_step)), "a proof of the last step is missing"
@@ -257,6 +261,8 @@ def main():
                        "host_cores_per_rank": share, "blocking_sync": os.environ.get("SHP_BLOCKING_SYNC") == "1",
                        "parallelism": f"proofs sharded over {n_gpus} GPU(s), no collective"},
             "p50_latency_ms": 1e3 * lat[len(lat) // 2] if lat else None,
+            "latency_proofs": len(lat),
+            "phase_us_p50": phase_us_p50,          # host wall time per prover phase of a lone proof (median)
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "avg_launch_us": 1e6 * avg_s if cnt else None, "rocprof_avg_launch_us": rocprof_avg_us,

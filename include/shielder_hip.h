@@ -229,6 +229,11 @@ int32_t shp_verify(const shp_pk* pk, const uint8_t* proof, size_t proof_len, con
 int32_t shp_prover_profile(shp_prover* p, int32_t enable);
 int32_t shp_prover_profile_read(shp_prover* p, uint32_t index, const char** name, uint64_t* launches,
                                 double* total_ms);
+/* Host-side phase clock of the LAST proof of this lane (shp_prover_profile(p, 1), or 2 = the phase clock alone,
+ * without HIP events in the stream): phase `index` = name and wall time in
+ * microseconds, in proof order (witness program, upload, advice commitments, lookups, grand products, quotient,
+ * evaluations, W, W'); SHP_ERR_INVALID_ARG past the last phase.  The per-phase split of SURVEY.md 8d config 2. */
+int32_t shp_prover_phase_read(shp_prover* p, uint32_t index, const char** name, double* us);
 /* poseidon::off_circuit::hash on the host (shielder_bindings/src/hash.rs:17-26): 32-byte LE canonical */
 int32_t shp_poseidon2_hash_host(const uint8_t* inputs_le32, uint32_t arity, uint8_t out_le32[32]);
 

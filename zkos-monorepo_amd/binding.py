@@ -380,7 +380,18 @@ class Prover:
         _check(lib().shp_prover_witness_threads(self.h, C.c_uint32(n)))
 
     def profile(self, enable=True):
-        _check(lib().shp_prover_profile(self.h, C.c_int32(1 if enable else 0)))
+        """True / 1: HIP-event kernel timers + phase clock; 2: the phase clock alone; False / 0: off"""
+        _check(lib().shp_prover_profile(self.h, C.c_int32(int(enable))))
+
+    def phases(self):
+        """host phase clock of the last proof (profile(True) first): [(name, microseconds)] in proof order"""
+        out, i = [], 0
+        while True:
+            name, us = C.c_char_p(), C.c_double()
+            if lib().shp_prover_phase_read(self.h, C.c_uint32(i), C.byref(name), C.byref(us)) != SHP_OK:
+                return out
+            out.append((name.value.decode(), us.value))
+            i += 1
 
     def profile_read(self):
         """{kernel family: (launches, total_ms)} measured with HIP events on the lane's stream"""

@@ -607,6 +607,8 @@ struct shp_prover {
     // a pool's cross-lane MSM combiner (null: this lane launches its own commitments) and the event that hands
     // the lane's stream position over to it
     bool throughput = false;               // shp_prover_mode(1): scheduling choices of a pool lane
+    bool keep_phases = false;
+    std::vector<std::pair<const char*, double>> last_phases;   // host phase clock of the last proof (profiling on)
     shp::MsmCombiner* comb = nullptr;
     bool comb_profile_owner = false;
     hipEvent_t comb_event = nullptr;
@@ -733,11 +735,16 @@ static std::vector<Fr> interpolate(const std::vector<Fr>& xs, const std::vector<
 // host-side phase clock (SHP_PHASE_TRACE=1): wall time between phase marks, printed per proof
 namespace {
 struct PhaseClock {
-    bool on;
+    bool on, print;
     std::chrono::steady_clock::time_point t0, last;
     std::vector<std::pair<const char*, double>> marks;
+    std::vector<std::pair<const char*, double>>* keep;      // the prover's copy of the last proof's phases (profiling on)
     double wait0;
-    PhaseClock() : on(getenv("SHP_PHASE_TRACE") != nullptr), wait0(shp::wait_us_accum()) { t0 = last = std::chrono::steady_clock::now(); }
+    explicit PhaseClock(std::vector<std::pair<const char*, double>>* keep_ = nullptr)
+        : print(getenv("SHP_PHASE_TRACE") != nullptr), keep(keep_), wait0(shp::wait_us_accum()) {
+        on = print || keep;
+        t0 = last = std::chrono::steady_clock::now();
+    }
     void mark(const char* name) {
         if (!on) return;
         auto now = std::chrono::steady_clock::now();
@@ -745,7 +752,8 @@ struct PhaseClock {
         last = now;
     }
     ~PhaseClock() {
-        if (!on) return;
+        if (keep) *keep = marks;
+        if (!print) return;
         double tot = std::chrono::duration<double, std::micro>(last - t0).count();
         fprintf(stderr, "[phases] total %.0f us (%.0f waiting for the stream):", tot, shp::wait_us_accum() - wait0);
         for (auto& m : marks) fprintf(stderr, " %s=%.0f", m.first, m.second);
@@ -810,7 +818,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     uint64_t ctr = 0;
     auto draw = [&]() { return fr_draw(key, ctr++); };
 
-    PhaseClock pc;
+    PhaseClock pc(pr->keep_phases ? &pr->last_phases : nullptr);
     pr->stage_off = 0;                                  // the previous proof's copies have all completed
     auto h2d = [&](void* dst, const void* src, size_t bytes) {
         if (!bytes) return;
@@ -1367,7 +1375,8 @@ int32_t shp_prover_mode(shp_prover* p, uint32_t mode) {
 int32_t shp_prover_profile(shp_prover* p, int32_t enable) {
     return guarded([&] {
         SHP_REQUIRE(p, SHP_ERR_INVALID_ARG, "prover_profile: null prover");
-        p->timers.enabled = enable != 0;
+        p->timers.enabled = enable == 1;                     // 2: the phase clock alone (no events in the stream)
+        p->keep_phases = enable != 0;
         p->timers.reset();
         if (p->comb && p->comb_profile_owner) {              // idle pool assumed (bench toggles between steps)
             p->comb->timers.enabled = enable != 0;
@@ -1396,6 +1405,14 @@ void shp_prover_attach_combiner(shp_prover* p, shp::MsmCombiner* c, bool profile
 }
 
 extern "C" {
+
+int32_t shp_prover_phase_read(shp_prover* p, uint32_t index, const char** name, double* us) {
+    return guarded([&] {
+        SHP_REQUIRE(p && index < p->last_phases.size(), SHP_ERR_INVALID_ARG, "prover_phase_read: no such phase");
+        if (name) *name = p->last_phases[index].first;
+        if (us) *us = p->last_phases[index].second;
+    });
+}
 
 int32_t shp_prover_destroy(shp_prover* p) {
     return guarded([&] { delete p; });
