@@ -301,9 +301,6 @@ F12 final_exp_fast(const F12& in) {
     return mul(t0, s1);
 }
 
-F12 miller(const G1Affine& p, const G2A& q);
-G2A g2_add(const G2A& a, const G2A& b);
-
 // once per process: the structured exponentiation against the definition -- an accepting pair, a rejecting value,
 // and the order of the result (it must lie in the r-torsion)
 bool final_exp_selfcheck() {
@@ -363,20 +360,6 @@ void g2_to_bytes(const G2A& q, uint8_t out[128]) {
 }
 
 // ------------------------------------------------------------------------------ G1 helpers (host)
-G1X g1_mul_fr(const G1X& p, const Fr& k_mont) {
-    const Fr k = k_mont.to_raw();
-    G1X acc = G1X::inf();
-    bool started = false;
-    for (int i = 253; i >= 0; i--) {
-        if (started) acc = g1_dbl(acc);
-        if ((k.l[i >> 5] >> (i & 31)) & 1) {
-            acc = started ? g1_add(acc, p) : p;
-            started = true;
-        }
-    }
-    return acc;
-}
-
 // sum_i k_i P_i on the host: Straus with 4-bit windows (one shared doubling chain, 15 multiples per point).
 // The SHPLONK check is one linear combination of every commitment of the proof and the key (~60 points):
 // evaluated as separate double-and-add chains it was 14 ms of a 19 ms verification.
