@@ -219,10 +219,16 @@ def test_msm_edge_cases(shp, oracle, gpu_ctx):
     m.close()
 
 
-def test_msm_2_20_matches_oracle(shp, oracle, gpu_ctx):
-    """BASELINE config 4 lower size against the multi-threaded oracle (a few seconds of CPU)"""
+# MICRO_LOG_NS=20,22,24 widens the two standalone-config tests to the upper sizes (a soak run: the CPU port needs ~10 s and
+# 1 GB for the 2^24 MSM); the default suite runs 2^20
+_MICRO = [int(x) for x in __import__("os").environ.get("MICRO_LOG_NS", "20").split(",")]
+
+
+@pytest.mark.parametrize("log_n", _MICRO)
+def test_msm_2_20_matches_oracle(shp, oracle, gpu_ctx, log_n):
+    """BASELINE config 4 against the multi-threaded oracle (a few seconds of CPU at 2^20)"""
     import torch
-    n = 1 << 20
+    n = 1 << log_n
     osrs = oracle.srs_synthetic(13, 987654321)
     reps = n // osrs.n
     # distinct-enough bases: tile the 8192 synthetic points (the MSM does not care about repeats)
@@ -240,7 +246,7 @@ def test_msm_2_20_matches_oracle(shp, oracle, gpu_ctx):
     gpu_s = (time.perf_counter() - t0) / 3
     t0 = time.perf_counter(); want = oracle.msm(bases, s); cpu_s = time.perf_counter() - t0
     assert np.array_equal(got, want)
-    _record("config4_msm_2_20", {"n": n, "gpu_ms": 1e3 * gpu_s, "cpu_port_ms": 1e3 * cpu_s, "cpu_threads": oracle.num_threads(),
+    _record(f"config4_msm_2_{log_n}", {"n": n, "gpu_ms": 1e3 * gpu_s, "cpu_port_ms": 1e3 * cpu_s, "cpu_threads": oracle.num_threads(),
                                   "speedup": cpu_s / gpu_s, "alg_GBps": 96 * n / gpu_s / 1e9})
     m.close()
     del torch
@@ -258,16 +264,20 @@ def _record(name, obj):
         pass
 
 
-def test_ntt_2_20_vs_cpu_port(shp, oracle, gpu_ctx):
-    """BASELINE config 5 lower size: parity with the oracle and the GPU / CPU-port timing"""
+@pytest.mark.parametrize("log_n", _MICRO)
+def test_ntt_2_20_vs_cpu_port(shp, oracle, gpu_ctx, log_n):
+    """BASELINE config 5: parity with the oracle and the GPU / CPU-port timing"""
     import time
     import torch
-    log_n, n = 20, 1 << 20
+    n = 1 << log_n
     a = rand_fr(oracle, n, 55)
     t = shp.to_device(a)
     gpu_ctx.ntt(t, log_n)
     got = shp.to_host(t).reshape(n, 4).copy()
-    # GPU timing first: the OpenMP oracle leaves its threads spinning for a while afterwards
+    # GPU timing first: the OpenMP oracle leaves its threads spinning for a while afterwards; a few untimed transforms
+    # bring an idle GPU up to its clocks (the first ~20 ms of work after idle run several times slower)
+    for _ in range(20):
+        gpu_ctx.ntt(t, log_n)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(10):
@@ -276,7 +286,7 @@ def test_ntt_2_20_vs_cpu_port(shp, oracle, gpu_ctx):
     gpu_s = (time.perf_counter() - t0) / 10
     t0 = time.perf_counter(); want = oracle.ntt(a, log_n); cpu_s = time.perf_counter() - t0
     assert np.array_equal(got, want)
-    _record("config5_ntt_2_20", {"n": n, "gpu_ms": 1e3 * gpu_s, "cpu_port_ms": 1e3 * cpu_s, "cpu_threads": oracle.num_threads(),
+    _record(f"config5_ntt_2_{log_n}", {"n": n, "gpu_ms": 1e3 * gpu_s, "cpu_port_ms": 1e3 * cpu_s, "cpu_threads": oracle.num_threads(),
                                   "speedup": cpu_s / gpu_s, "alg_GBps": 64 * n / gpu_s / 1e9})
 
 
