@@ -168,3 +168,58 @@ def test_native_wire_codec_matches_the_python_mirror():
             d = json.loads(B.tee_encode_proof_response(ctype, proof, inst))
             assert base64.b64decode(d["EncryptedProof"]["proof"]) == proof
             assert base64.b64decode(d["EncryptedProof"]["pub_inputs"]) == S.withdraw_pub_inputs_json(inst, pub)
+
+
+def test_native_wire_codec_fuzz():
+    """random damage to valid frames: the native parser never accepts what the Python mirror of the protocol rejects (and
+    returns the same witness when both accept); it may be stricter (it refuses number forms and escapes serde would take
+    but no client produces)"""
+    import random
+    B = importlib.import_module("zkos-monorepo_amd.binding")
+    rnd = random.Random(2024)
+    height = 2
+    base = {c: json.dumps(make_request(make_inputs(height, bump=i), c)).encode() for i, c in enumerate(("Withdraw", "Deposit"))}
+    base["NewAccount"] = json.dumps(make_request({f: le(77 + i) for i, f in enumerate(S.NEW_ACCOUNT_INPUT_FIELDS)}, "NewAccount")).encode()
+
+    def mirror(body):
+        try:
+            req = json.loads(body)
+            if not isinstance(req, dict) or set(req) != {"GenerateProof"}:
+                return None
+            ctype, inputs = S.decode_payload(S._bytes_field(req["GenerateProof"].get("payload"), "payload"))
+            if not isinstance(inputs, dict):
+                return None
+            return ctype, S.withdraw_witness_bytes(inputs, height, S.INPUT_FIELDS[ctype])
+        except (S.ProtocolError, ValueError, KeyError, TypeError, AttributeError, RecursionError):
+            return None
+
+    accepted = stricter = 0
+    for it in range(1500):
+        body = bytearray(base[rnd.choice(list(base))])
+        for _ in range(rnd.choice((1, 1, 1, 2, 3))):
+            kind = rnd.randrange(5)
+            pos = rnd.randrange(len(body))
+            if kind == 0:
+                body[pos] = rnd.choice(b'0123456789,[]{}":x -')
+            elif kind == 1:
+                del body[pos:pos + rnd.randrange(1, 6)]
+            elif kind == 2:
+                body[pos:pos] = bytes(rnd.choice(b'0123456789,[]{}":') for _ in range(rnd.randrange(1, 4)))
+            elif kind == 3:
+                body = body[:pos]
+            else:
+                body[pos] ^= 1 << rnd.randrange(8)
+        body = bytes(body)
+        want = mirror(body)
+        try:
+            kind_, ctype, wit = B.tee_decode_request(body, height)
+            got = (ctype, wit) if kind_ == B.TEE_GENERATE_PROOF else None
+        except B.ShpError as e:
+            assert e.code == 4
+            got = None
+        if got is not None:
+            accepted += 1
+            assert want is not None and got == want, (it, body[:80])
+        elif want is not None:
+            stricter += 1
+    assert accepted > 20 and stricter <= 15, (accepted, stricter)

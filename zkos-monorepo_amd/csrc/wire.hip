@@ -61,6 +61,7 @@ void bytes_array(Cur& c, std::vector<uint8_t>& out) {
     for (;;) {
         ws(c);
         if (c.p >= c.e || *c.p < '0' || *c.p > '9') bad("byte array: expected a number");
+        if (*c.p == '0' && c.p + 1 < c.e && c.p[1] >= '0' && c.p[1] <= '9') bad("byte array: leading zero");
         uint32_t v = 0;
         while (c.p < c.e && *c.p >= '0' && *c.p <= '9') {
             v = v * 10 + (*c.p++ - '0');
