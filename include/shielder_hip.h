@@ -203,12 +203,12 @@ int32_t shp_prove(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, c
 /* Host threads the lane uses for the witness program (the reference's `synthesize`, rayon in its
  * multithreading feature): the program is cut into independent tasks once per lane (Poseidon2
  * permutations of the Merkle levels run side by side).  Default 8 (env SHP_WITNESS_THREADS); a
- * proving pool divides them over its lanes and sets 1 above 4 lanes -- throughput does not need
+ * proving pool divides them over its lanes (1 each from 8 lanes up) -- throughput does not need
  * them, latency does. */
 int32_t shp_prover_witness_threads(shp_prover* p, uint32_t threads);
 /* Scheduling bias of a lane: 0 = latency (default: short per-lane addition chains in the commitment
  * kernels, so a lone proof fills the chip), 1 = throughput (long chains, least reduction work; what a
- * proving pool with more than 4 lanes sets, together with one witness thread).  Proof bytes do not depend on it. */
+ * proving pool with more than 8 lanes sets, together with one witness thread).  Proof bytes do not depend on it. */
 int32_t shp_prover_mode(shp_prover* p, uint32_t mode);
 /* ProverKnowledge::serialize_public_input without proving -- the `*_pub_inputs` entry points of the bindings
  * (/root/reference/crates/shielder_bindings/src/circuits/withdraw.rs:150-174; the TEE answers every request with

@@ -47,7 +47,7 @@ struct shp_pool {
     uint64_t next_ticket = 1;
     bool stopping = false;
     std::atomic<uint64_t> proofs_done{0};
-    shp::MsmCombiner* comb = nullptr;      // lanes > 4: one MSM launch serves every lane waiting at a commitment
+    shp::MsmCombiner* comb = nullptr;      // SHP_POOL_COMBINE=1: one MSM launch serves every lane waiting at a commitment
 
     void worker(shp_prover* lane) {
         (void)hipSetDevice(device);
@@ -91,6 +91,10 @@ int32_t shp_pool_create(shp_pk* pk, uint32_t lanes, uint32_t queue_cap, shp_pool
         int32_t rc = shp_pk_info(pk, &k, &p->n_inputs, &p->n_instances, &p->proof_len);
         SHP_REQUIRE(rc == SHP_OK, rc, "pool_create: pk_info failed");
         p->queue_cap = queue_cap ? queue_cap : 100;      // the reference's task-pool bound
+        // pools above this many lanes schedule them for throughput (SHP_POOL_THROUGHPUT_ABOVE, default 8: measured on the
+        // serve path, latency-mode lanes win up to 8 lanes -- 6 lanes 1013 vs 934 proofs/s, 8 lanes 1134 vs 1101 -- draw
+        // level at 12 and lose at 16, 1218 vs 1304)
+        const uint32_t tp_above = getenv("SHP_POOL_THROUGHPUT_ABOVE") ? (uint32_t)atoi(getenv("SHP_POOL_THROUGHPUT_ABOVE")) : 8;
         for (uint32_t i = 0; i < lanes; i++) {
             shp_prover* pr = nullptr;
             rc = shp_prover_create(pk, &pr);
@@ -98,8 +102,8 @@ int32_t shp_pool_create(shp_pk* pk, uint32_t lanes, uint32_t queue_cap, shp_pool
                 for (auto* q : p->lanes) shp_prover_destroy(q);
                 throw shp::Error(rc, std::string("pool_create: ") + shp_last_error());
             }
-            if (lanes > 4) (void)shp_prover_mode(pr, 1);   // many lanes: one host thread each, long MSM chains
-            else if (lanes > 1) (void)shp_prover_witness_threads(pr, 8 / lanes);   // a few lanes share the helper threads' cores
+            if (lanes > tp_above) (void)shp_prover_mode(pr, 1);   // many lanes: one host thread each, long MSM chains
+            else if (lanes > 1) (void)shp_prover_witness_threads(pr, std::max<uint32_t>(1, 8 / lanes));   // a few lanes share the helper threads' cores
             p->lanes.push_back(pr);
         }
         // opt-in (SHP_POOL_COMBINE=1): on one MI355X the pool is not limited by the size of its MSM launches --
