@@ -207,7 +207,7 @@ int32_t shp_prove(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, c
  * them, latency does. */
 int32_t shp_prover_witness_threads(shp_prover* p, uint32_t threads);
 /* Scheduling bias of a lane: 0 = latency (default: short per-lane addition chains in the commitment
- * kernels, so a lone proof fills the chip), 1 = throughput (long chains, least reduction work; what a
+ * kernels, so a lone proof fills the chip), 1 = throughput (long chains, little reduction work; what a
  * proving pool with more than 8 lanes sets, together with one witness thread).  Proof bytes do not depend on it. */
 int32_t shp_prover_mode(shp_prover* p, uint32_t mode);
 /* ProverKnowledge::serialize_public_input without proving -- the `*_pub_inputs` entry points of the bindings

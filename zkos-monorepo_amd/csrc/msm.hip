@@ -1005,7 +1005,7 @@ shp::MsmCombiner* shp::msm_combiner_create(int device) {
     c->device = device;
     SHP_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
     c->ws.timers = &c->timers;
-    c->ws.min_waves = 256;                                         // throughput scheduling: long chains
+    c->ws.min_waves = 512;                                         // throughput scheduling: long chains
     MsmCombiner* raw = c.get();
     c->th = std::thread([raw] { raw->loop(); });
     return c.release();
