@@ -875,7 +875,9 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
     SHP_REQUIRE(busy_wgs < (1ull << 31), SHP_ERR_INVALID_ARG, "msm: launch too large");
     // T windows per lane: all of them when the launch fills the chip anyway (least tree overhead),
     // shorter chains for small launches (latency)
-    static const uint64_t base_waves = getenv("SHP_MSM_MIN_WAVES") ? (uint64_t)atol(getenv("SHP_MSM_MIN_WAVES")) : 1024;
+    // (measured: a lone proof's p50 is 2.45 / 2.27 / 2.22 / 2.21 / 2.27 / 2.30 / 2.46 ms at 256 / 384 / 512 / 640 / 768 /
+    // 1024 / 2048 waves; 16 pool lanes peak at 512 too)
+    static const uint64_t base_waves = getenv("SHP_MSM_MIN_WAVES") ? (uint64_t)atol(getenv("SHP_MSM_MIN_WAVES")) : 512;
     const uint64_t min_waves = ws.min_waves ? ws.min_waves : base_waves;
     const uint32_t cand[6] = {W, (W + 1) / 2, 8, 4, 2, 1};
     uint32_t T = 1;
