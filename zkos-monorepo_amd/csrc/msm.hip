@@ -879,10 +879,10 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
     // 1024 / 2048 waves; 16 pool lanes peak at 512 too)
     static const uint64_t base_waves = getenv("SHP_MSM_MIN_WAVES") ? (uint64_t)atol(getenv("SHP_MSM_MIN_WAVES")) : 512;
     const uint64_t min_waves = ws.min_waves ? ws.min_waves : base_waves;
-    const uint32_t cand[6] = {W, (W + 1) / 2, 8, 4, 2, 1};
-    uint32_t T = 1;
-    for (uint32_t t : cand)
-        if (t <= W && busy_wgs * (MSM_THREADS / 64) * ceil_div(W, t) >= min_waves) { T = t; break; }
+    // the fewest window groups that reach min_waves, the windows spread evenly over them
+    const uint64_t per_group = busy_wgs * (MSM_THREADS / 64);
+    const uint32_t groups = (uint32_t)std::min<uint64_t>(W, std::max<uint64_t>(1, (min_waves + per_group - 1) / per_group));
+    const uint32_t T = ceil_div(W, groups);
     const uint32_t gy = ceil_div(W, T);
     uint64_t parts = 0;
     for (uint32_t k = 0; k < n_jobs; k++) {
