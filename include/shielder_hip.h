@@ -100,6 +100,14 @@ int32_t shp_encode_calldata(const uint8_t* proof, size_t proof_len, const uint8_
 /* `batch` polynomials of 2^log_n elements each, contiguous, in place, natural order in and out.
  * inverse != 0: omega^{-1} and the 1/n scaling (lagrange_to_coeff). */
 int32_t shp_ntt_fr(shp_ctx* ctx, void* d_data, uint32_t log_n, uint32_t batch, int32_t inverse, void* stream);
+/* shp_ntt_fr for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  No counterpart in the reference.  Same arguments and results as shp_ntt_fr; the
+ * call itself performs no hipMalloc / hipFree: the ping-pong buffer of the multi-pass transform is a static
+ * 32 MiB device array inside the library (one copy per GPU, held until the process ends) and the twiddle
+ * tables it needs are built by shp_ctx_create.  Limits: log_n <= 20 and batch * 2^log_n <= 2^20 elements,
+ * SHP_ERR_INVALID_ARG beyond.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU
+ * (different streams or threads) race; calls ordered on one stream do not. */
+int32_t shp_ntt_fr_noalloc(shp_ctx* ctx, void* d_data, uint32_t log_n, uint32_t batch, int32_t inverse, void* stream);
 /* coeff_to_extended: d_in = batch x 2^k coefficients; d_out = batch x 2^ext_k evaluations on the
  * zeta-coset (coefficient i scaled by [1, zeta, zeta^2][i mod 3], zero-padded, forward NTT). */
 int32_t shp_coeff_to_extended(shp_ctx* ctx, const void* d_in, void* d_out, uint32_t k, uint32_t ext_k,

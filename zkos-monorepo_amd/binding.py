@@ -139,6 +139,13 @@ class Context:
                                 C.c_int32(1 if inverse else 0), _stream()))
         return t
 
+    def ntt_noalloc(self, t, log_n, batch=1, inverse=False):
+        """shp_ntt_fr_noalloc: the same transform through the library's static ping-pong array (no allocation)"""
+        assert t.is_cuda and t.numel() == batch * (1 << log_n) * 4
+        _check(lib().shp_ntt_fr_noalloc(self.h, _vp(t.data_ptr()), C.c_uint32(log_n), C.c_uint32(batch),
+                                        C.c_int32(1 if inverse else 0), _stream()))
+        return t
+
     def coeff_to_extended(self, t_in, k, ext_k, batch=1):
         import torch
         out = torch.empty(batch * (1 << ext_k) * 4, dtype=torch.int64, device=t_in.device)

@@ -184,6 +184,15 @@ int32_t shp_ctx_create(int32_t device, shp_ctx** out) {
         c->device = device;
         c->num_cus = prop.multiProcessorCount;
         SHP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        try {
+            ntt_static_setup(c.get());
+        } catch (...) {
+            ntt_static_teardown(c.get());
+            for (int d = 0; d < 2; d++)
+                if (c->ntt_small[d]) (void)hipFree(c->ntt_small[d]);
+            (void)hipStreamDestroy(c->stream);
+            throw;
+        }
         *out = c.release();
     });
 }
@@ -200,6 +209,7 @@ int32_t shp_ctx_destroy(shp_ctx* ctx) {
                 (void)hipFree(kv.second.hi[d]);
             }
         ctx->ntt_tmp.release();
+        ntt_static_teardown(ctx);
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
     });

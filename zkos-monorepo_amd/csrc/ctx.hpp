@@ -30,6 +30,12 @@ struct shp_ctx {
     shp::Fr* ntt_small[2] = {nullptr, nullptr};          // w_2048^j and its inverse powers
     std::map<uint32_t, shp::NttTables> ntt_tables;
     shp::DevBuf ntt_tmp;                                  // ping-pong buffer of the multi-pass NTT
+    // the allocation-free NTT entry point: powers of w_(2^20) split as lo[j] = w^j, hi[j] = w^(1024 j)
+    // (j < 1024, [0] forward, [1] inverse; every smaller domain's twiddles are a stride of these), and this
+    // device's address of the library's static ping-pong array -- both set up once by shp_ctx_create
+    shp::Fr* ntt_master_lo[2] = {nullptr, nullptr};
+    shp::Fr* ntt_master_hi[2] = {nullptr, nullptr};
+    shp::Fr* ntt_static_tmp = nullptr;
     shp::Fr zeta, zeta2;                                  // coset generator of the extended domain
 
     hipStream_t pick(void* s) const { return s ? reinterpret_cast<hipStream_t>(s) : stream; }
@@ -40,6 +46,10 @@ const NttTables& ntt_tables_for(shp_ctx* ctx, uint32_t log_n);
 Fr fr_root_of_unity(uint32_t k);     // primitive 2^k-th root (host)
 Fr fr_zeta();                         // 7^((r-1)/3)
 Fr fr_delta();                        // 7^(2^28)
+// set-up / tear-down of what shp_ntt_fr_noalloc needs (called by shp_ctx_create / shp_ctx_destroy with the
+// context's device current)
+void ntt_static_setup(shp_ctx* ctx);
+void ntt_static_teardown(shp_ctx* ctx);
 
 // launchers used by the C ABI and the prover
 struct NttOpts {

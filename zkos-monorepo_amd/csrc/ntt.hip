@@ -32,6 +32,7 @@ struct PassParams {
     Fr* dst;
     size_t src_stride, dst_stride;
     uint32_t log_n, s, lo_bits, c, s1, s2, h;
+    uint32_t tw_shift;        // the twiddle tables hold powers of w_(2^(log_n + tw_shift)): exponents are shifted up
     uint32_t in_len;
     int is_first, is_final, pre_pattern, post_pattern, do_scale;
     const Fr* small_tw;
@@ -153,11 +154,11 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
         if (!p.is_final) {
             uint32_t lo = lo_base | v;
             go = ((size_t)hi << (s + p.lo_bits)) | ((size_t)kp << p.lo_bits) | lo;
-            uint64_t et = ((uint64_t)kp * lo) << hi_bits;
+            uint64_t et = (((uint64_t)kp * lo) << hi_bits) << p.tw_shift;
             if (et) {
                 // domains up to 2^18 keep every power in one (L2-resident) table: one product instead of two
                 Fr tw = gload(p.tw_lo + (et & ((1u << p.h) - 1)));
-                if (p.h < p.log_n) tw = gload(p.tw_hi + (et >> p.h)) * tw;
+                if (p.h < p.log_n + p.tw_shift) tw = gload(p.tw_hi + (et >> p.h)) * tw;
                 val = val * tw;
             }
         } else {
@@ -226,15 +227,19 @@ static Fr* upload_powers(const Fr& base, size_t count) {
     return d;
 }
 
+// tables shared by every size (caller holds ctx->mu)
+static void ntt_small_tables(shp_ctx* ctx) {
+    if (ctx->ntt_small[0]) return;
+    Fr w = fr_root_of_unity(11);
+    ctx->ntt_small[0] = upload_powers(w, 1024);
+    ctx->ntt_small[1] = upload_powers(Fr::inv(w), 1024);
+    ctx->zeta = fr_zeta();
+    ctx->zeta2 = Fr::sqr(ctx->zeta);
+}
+
 const NttTables& ntt_tables_for(shp_ctx* ctx, uint32_t log_n) {
     std::lock_guard<std::mutex> g(ctx->mu);
-    if (!ctx->ntt_small[0]) {
-        Fr w = fr_root_of_unity(11);
-        ctx->ntt_small[0] = upload_powers(w, 1024);
-        ctx->ntt_small[1] = upload_powers(Fr::inv(w), 1024);
-        ctx->zeta = fr_zeta();
-        ctx->zeta2 = Fr::sqr(ctx->zeta);
-    }
+    ntt_small_tables(ctx);
     auto it = ctx->ntt_tables.find(log_n);
     if (it != ctx->ntt_tables.end()) return it->second;
     NttTables t;
@@ -250,11 +255,9 @@ const NttTables& ntt_tables_for(shp_ctx* ctx, uint32_t log_n) {
     return ctx->ntt_tables.emplace(log_n, t).first->second;
 }
 
-void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_t batch, const NttOpts& o,
-                hipStream_t st, Fr* tmp_in) {
-    SHP_REQUIRE(log_n >= 1 && log_n <= 27, SHP_ERR_INVALID_ARG, "ntt: log_n out of range [1,27]");
-    if (batch == 0) return;
-    const NttTables& T = ntt_tables_for(ctx, log_n);
+// `T`: the inter-pass twiddle tables, powers of w_(2^(log_n + tw_shift))
+static void ntt_launch_with(shp_ctx* ctx, const NttTables& T, uint32_t tw_shift, const Fr* d_in, Fr* d_out, uint32_t log_n,
+                            uint32_t batch, const NttOpts& o, hipStream_t st, Fr* tmp_in) {
     const size_t N = (size_t)1 << log_n;
     const int dir = o.inverse ? 1 : 0;
 
@@ -302,6 +305,7 @@ void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_
             p.c = cmax < p.lo_bits ? cmax : p.lo_bits;
         }
         p.h = T.h;
+        p.tw_shift = tw_shift;
         p.in_len = in_len;
         p.pre_pattern = o.pre_pattern;
         p.post_pattern = o.post_pattern;
@@ -333,4 +337,71 @@ void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_
     }
 }
 
+void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_t batch, const NttOpts& o,
+                hipStream_t st, Fr* tmp_in) {
+    SHP_REQUIRE(log_n >= 1 && log_n <= 27, SHP_ERR_INVALID_ARG, "ntt: log_n out of range [1,27]");
+    if (batch == 0) return;
+    ntt_launch_with(ctx, ntt_tables_for(ctx, log_n), 0, d_in, d_out, log_n, batch, o, st, tmp_in);
+}
+
+// ------------------------------------------------------------------ the entry point that allocates nothing
+// Callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it)
+// get shp_ntt_fr with every piece of device memory beyond their own buffer provided by the library up front:
+//   * the ping-pong buffer of the multi-pass transform is this file-scope device array (each GPU the library runs
+//     on holds its own copy until the process ends);
+//   * the inter-pass twiddles come from two 1024-entry tables of powers of w_(2^20) built by shp_ctx_create
+//     (a domain of 2^log_n points uses every 2^(20 - log_n)-th power).
+constexpr uint32_t NTT_STATIC_LOG = 20;                                   // at most 2^20 elements (32 MiB) per call
+static __device__ __align__(256) unsigned char scratch[((size_t)1 << NTT_STATIC_LOG) * sizeof(Fr)];
+
+void ntt_static_setup(shp_ctx* ctx) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ntt_small_tables(ctx);
+    // `scratch` is a host-side stand-in for the symbol; this device's copy of the array lives at the address
+    // the runtime reports here (the context's device is current)
+    void* ptr = nullptr;
+    SHP_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    SHP_REQUIRE(ptr, SHP_ERR_HIP, "ntt: the static ping-pong array has no device address");
+    ctx->ntt_static_tmp = reinterpret_cast<Fr*>(ptr);
+    const Fr w = fr_root_of_unity(NTT_STATIC_LOG), wi = Fr::inv(w);
+    ctx->ntt_master_lo[0] = upload_powers(w, 1024);
+    ctx->ntt_master_lo[1] = upload_powers(wi, 1024);
+    ctx->ntt_master_hi[0] = upload_powers(pow2k(w, 10), 1024);
+    ctx->ntt_master_hi[1] = upload_powers(pow2k(wi, 10), 1024);
+}
+
+void ntt_static_teardown(shp_ctx* ctx) {
+    for (int d = 0; d < 2; d++) {
+        if (ctx->ntt_master_lo[d]) (void)hipFree(ctx->ntt_master_lo[d]);
+        if (ctx->ntt_master_hi[d]) (void)hipFree(ctx->ntt_master_hi[d]);
+        ctx->ntt_master_lo[d] = ctx->ntt_master_hi[d] = nullptr;
+    }
+    ctx->ntt_static_tmp = nullptr;
+}
+
 }  // namespace shp
+
+extern "C" int32_t shp_ntt_fr_noalloc(shp_ctx* ctx, void* d_data, uint32_t log_n, uint32_t batch, int32_t inverse,
+                                      void* stream) {
+    using namespace shp;
+    return guarded([&] {
+        SHP_REQUIRE(ctx && d_data, SHP_ERR_INVALID_ARG, "ntt_noalloc: null argument");
+        SHP_REQUIRE(log_n >= 1 && log_n <= NTT_STATIC_LOG, SHP_ERR_INVALID_ARG,
+                    "ntt_noalloc: log_n out of range [1,20] (the static ping-pong array holds 2^20 elements)");
+        SHP_REQUIRE(((uint64_t)batch << log_n) <= (1ull << NTT_STATIC_LOG), SHP_ERR_INVALID_ARG,
+                    "ntt_noalloc: batch * 2^log_n exceeds the 2^20 elements of the static ping-pong array");
+        SHP_REQUIRE(ctx->ntt_static_tmp && ctx->ntt_master_lo[0], SHP_ERR_INTERNAL, "ntt_noalloc: context not set up");
+        if (batch == 0) return;
+        NttTables T;
+        T.log_n = log_n;
+        T.h = 10;
+        for (int d = 0; d < 2; d++) { T.lo[d] = ctx->ntt_master_lo[d]; T.hi[d] = ctx->ntt_master_hi[d]; }
+        T.n_inv = Fr::inv(Fr::from_u64(1ull << log_n));
+        NttOpts o;
+        o.inverse = inverse != 0;
+        // every element of the ping-pong array that a pass reads was written by the pass before it in this same
+        // call: nothing needs clearing between calls
+        ntt_launch_with(ctx, T, NTT_STATIC_LOG - log_n, (const Fr*)d_data, (Fr*)d_data, log_n, batch, o, ctx->pick(stream),
+                        ctx->ntt_static_tmp);
+    });
+}
