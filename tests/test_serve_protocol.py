@@ -132,6 +132,10 @@ def test_native_wire_codec_matches_the_python_mirror():
                list(json.dumps(dict(inputs, unknown=[1, 2]), indent=1).encode())}
     body = json.dumps({"GenerateProof": {"payload": list(json.dumps(payload, indent=2).encode())}}, indent=3).encode()
     assert B.tee_decode_request(body, 2)[2] == S.withdraw_witness_bytes(inputs, 2)
+    # ignored fields: every JSON value form, nested up to the depth limit, repeated unknown keys
+    ok_extra = b'{"u":[-0.5e+3,true,false,null,"s\\n\\"",{},[],{"k":[{"z":0}]}],"u":1,"v":' + b"[" * 128 + b"]" * 128 + b","
+    body = json.dumps(make_request(inputs, "Withdraw")).encode().replace(b'{"payload"', ok_extra + b'"payload"', 1)
+    assert B.tee_decode_request(body, 2)[2] == S.withdraw_witness_bytes(inputs, 2)
     assert B.tee_decode_request(b'"Ping"', 2) == (B.TEE_PING, None, None)
     assert B.tee_decode_request(b'  "TeePublicKey"\n', 2) == (B.TEE_PUBLIC_KEY, None, None)
 
@@ -156,6 +160,23 @@ def test_native_wire_codec_matches_the_python_mirror():
     bad.append(b'{"GenerateProof":{}}')
     bad.append(b'{"Generate":{"payload":[]}}')
     bad.append(b"")
+    # an ignored field nested beyond serde_json's depth limit (128): refused, and never by exhausting the stack --
+    # 100 000 levels are a 200 KB frame, far below the 8 MB frame cap
+    for depth in (129, 100000):
+        for o, c in (("[", "]"), ('{"a":', "}")):
+            bad.append(b'{"GenerateProof":{"x":' + o.encode() * depth + b"1" + c.encode() * depth + b',"payload":[]}}')
+    bad.append(b'{"GenerateProof":{"x":' + b"[" * 100000)                         # deep and truncated
+    dup = json.dumps(make_request(make_inputs(2), "Withdraw"))
+    bad.append(dup.replace('{"GenerateProof":', '{"GenerateProof":{"payload":[]},"GenerateProof":', 1).encode())   # variant twice
+    bad.append(dup.replace('"payload":', '"payload":[],"payload":', 1).encode())                                    # field twice
+    twice = make_inputs(2)
+    inner_dup = json.dumps(twice).replace('"id":', '"id":' + json.dumps(twice["id"]) + ',"id":', 1)
+    pl = {"circuit_type": "Withdraw", "user_public_key": [], "circuit_inputs": list(inner_dup.encode())}
+    bad.append(json.dumps({"GenerateProof": {"payload": list(json.dumps(pl).encode())}}).encode())                 # witness field twice
+    pl2 = json.dumps({"circuit_type": "Withdraw", "user_public_key": [], "circuit_inputs": list(json.dumps(twice).encode())})
+    bad.append(json.dumps({"GenerateProof": {"payload": list(pl2.replace('"circuit_type":', '"circuit_type":"Deposit","circuit_type":', 1).encode())}}).encode())
+    for junk in (b"nul", b"tru", b"True", b"01", b"1.", b"-", b"1e", b"+1", b".5", b"0x10", b"NaN", b"'a'", b'"\\q"', b'"ab"'):
+        bad.append(b'{"GenerateProof":{"x":' + junk + b',"payload":[]}}')                                          # not JSON values
     for b in bad:
         with pytest.raises(B.ShpError) as e:
             B.tee_decode_request(b, 2)
@@ -183,7 +204,7 @@ def test_native_wire_codec_fuzz():
 
     def mirror(body):
         try:
-            req = json.loads(body)
+            req = S.loads_strict(body)
             if not isinstance(req, dict) or set(req) != {"GenerateProof"}:
                 return None
             ctype, inputs = S.decode_payload(S._bytes_field(req["GenerateProof"].get("payload"), "payload"))
@@ -223,3 +244,15 @@ def test_native_wire_codec_fuzz():
         elif want is not None:
             stricter += 1
     assert accepted > 20 and stricter <= 15, (accepted, stricter)
+
+
+def test_python_mirror_refuses_what_serde_refuses():
+    """the Python path of the server (used when the native codec is unavailable) agrees with the native one on duplicate
+    fields and on nesting deep enough to exhaust a recursive parser"""
+    with pytest.raises(S.ProtocolError):
+        S.loads_strict(b'{"a":1,"a":2}')
+    with pytest.raises(S.ProtocolError):
+        S.loads_strict(b"[" * 100000 + b"]" * 100000)
+    with pytest.raises(S.ProtocolError):
+        S.loads_strict(b'{"a":')
+    assert S.loads_strict(b'{"a":{"a":1},"b":[{"a":2}]}') == {"a": {"a": 1}, "b": [{"a": 2}]}

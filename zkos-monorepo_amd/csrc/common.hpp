@@ -126,6 +126,8 @@ struct MsmCombiner;
 MsmCombiner* msm_combiner_create(int device);
 void msm_combiner_destroy(MsmCombiner* c);
 }  // namespace shp
+// internal (not part of the C ABI): the GPU a proving key lives on
+int shp_pk_device(const shp_pk* pk);
 // internal (not part of the C ABI): commitments of this lane go through the pool's combiner; `profile_owner` lanes
 // report the combiner's kernel timers with their own (shp_prover_profile_read)
 void shp_prover_attach_combiner(shp_prover* p, shp::MsmCombiner* c, bool profile_owner);

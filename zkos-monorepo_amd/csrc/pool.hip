@@ -86,7 +86,9 @@ int32_t shp_pool_create(shp_pk* pk, uint32_t lanes, uint32_t queue_cap, shp_pool
         SHP_REQUIRE(pk && out && lanes >= 1 && lanes <= 64, SHP_ERR_INVALID_ARG, "pool_create: bad arguments");
         std::unique_ptr<shp_pool> p(new shp_pool);
         p->pk = pk;
-        SHP_HIP(hipGetDevice(&p->device));
+        // the key's device, not the calling thread's: an FFI thread that never called hipSetDevice sits on device 0
+        p->device = shp_pk_device(pk);
+        SHP_HIP(hipSetDevice(p->device));
         uint32_t k = 0;
         int32_t rc = shp_pk_info(pk, &k, &p->n_inputs, &p->n_instances, &p->proof_len);
         SHP_REQUIRE(rc == SHP_OK, rc, "pool_create: pk_info failed");

@@ -43,8 +43,11 @@ std::string str(Cur& c) {
             if (c.p + 1 >= c.e) bad("truncated escape");
             const char x = (char)c.p[1];
             if (x == 'u') bad("unicode escapes are not part of this protocol");
+            if (x != '"' && x != '\\' && x != '/' && x != 'n' && x != 't' && x != 'r' && x != 'b' && x != 'f') bad("invalid escape");
             s.push_back(x == 'n' ? '\n' : x == 't' ? '\t' : x == 'r' ? '\r' : x == 'b' ? '\b' : x == 'f' ? '\f' : x);
             c.p += 2;
+        } else if (*c.p < 0x20) {
+            bad("control character in a string");
         } else {
             s.push_back((char)*c.p++);
         }
@@ -74,24 +77,68 @@ void bytes_array(Cur& c, std::vector<uint8_t>& out) {
         return;
     }
 }
-void skip(Cur& c) {                                          // any JSON value
-    ws(c);
-    if (c.p >= c.e) bad("truncated value");
-    if (*c.p == '"') { (void)str(c); return; }
-    if (*c.p == '[' || *c.p == '{') {
-        const char open = (char)*c.p, close = open == '[' ? ']' : '}';
+// JSON number grammar (RFC 8259): -? (0 | [1-9][0-9]*) (. [0-9]+)? ([eE] [+-]? [0-9]+)?
+void number(Cur& c) {
+    auto digits = [&] {
+        if (c.p >= c.e || *c.p < '0' || *c.p > '9') bad("malformed number");
+        while (c.p < c.e && *c.p >= '0' && *c.p <= '9') c.p++;
+    };
+    if (c.p < c.e && *c.p == '-') c.p++;
+    if (c.p < c.e && *c.p == '0') c.p++;
+    else digits();
+    if (c.p < c.e && *c.p == '.') { c.p++; digits(); }
+    if (c.p < c.e && (*c.p == 'e' || *c.p == 'E')) {
         c.p++;
-        if (peek(c, close)) { c.p++; return; }
+        if (c.p < c.e && (*c.p == '+' || *c.p == '-')) c.p++;
+        digits();
+    }
+}
+// Any JSON value of an ignored field.  Iterative: the open brackets are kept on an explicit stack of at most
+// MAX_DEPTH entries (serde_json refuses deeper documents at 128), so that no frame can exhaust the thread's stack.
+constexpr size_t MAX_DEPTH = 128;
+void skip(Cur& c) {
+    char open[MAX_DEPTH];
+    size_t depth = 0;
+    for (;;) {
+        // one value starts here
+        ws(c);
+        if (c.p >= c.e) bad("truncated value");
+        bool closed_one = true;                                  // a scalar, or an empty container, is complete
+        if (*c.p == '"') {
+            (void)str(c);
+        } else if (*c.p == '[' || *c.p == '{') {
+            if (depth == MAX_DEPTH) bad("nesting too deep");
+            const char o = (char)*c.p++;
+            if (peek(c, o == '[' ? ']' : '}')) {
+                c.p++;
+            } else {
+                open[depth++] = o;
+                if (o == '{') { (void)str(c); expect(c, ':'); }
+                closed_one = false;                              // its first member's value comes next
+            }
+        } else if (*c.p == '-' || (*c.p >= '0' && *c.p <= '9')) {
+            number(c);
+        } else {
+            const size_t left = (size_t)(c.e - c.p);
+            if (left >= 4 && memcmp(c.p, "true", 4) == 0) c.p += 4;
+            else if (left >= 4 && memcmp(c.p, "null", 4) == 0) c.p += 4;
+            else if (left >= 5 && memcmp(c.p, "false", 5) == 0) c.p += 5;
+            else bad("unexpected token");
+        }
+        if (!closed_one) continue;
+        // a value is complete: either another member follows in the innermost open container, or it closes
         for (;;) {
-            if (open == '{') { (void)str(c); expect(c, ':'); }
-            skip(c);
+            if (depth == 0) return;
             ws(c);
-            if (c.p < c.e && *c.p == ',') { c.p++; continue; }
-            expect(c, close);
-            return;
+            if (c.p < c.e && *c.p == ',') {
+                c.p++;
+                if (open[depth - 1] == '{') { (void)str(c); expect(c, ':'); }
+                break;                                           // next member's value
+            }
+            expect(c, open[depth - 1] == '[' ? ']' : '}');
+            depth--;
         }
     }
-    while (c.p < c.e && *c.p != ',' && *c.p != ']' && *c.p != '}' && *c.p != ' ' && *c.p != '\n') c.p++;   // number / literal
 }
 template <class F>
 void object(Cur& c, F on_key) {                               // on_key(key, cur) consumes the value
@@ -178,12 +225,19 @@ int32_t shp_tee_decode_request(const uint8_t* json, size_t len, uint32_t height,
             else bad("unknown request");
             return;
         }
+        // serde rejects a field that appears twice ("duplicate field") and an externally tagged enum with more
+        // than one key; ignored (unknown) fields may repeat
         std::vector<uint8_t> payload, inner, field;
-        bool have_payload = false;
+        bool have_payload = false, have_variant = false;
+        auto once = [](bool& flag) {
+            if (flag) bad("duplicate field");
+            flag = true;
+        };
         object(c, [&](const std::string& k, Cur& cc) {
             if (k != "GenerateProof") bad("unknown request");
+            once(have_variant);
             object(cc, [&](const std::string& k2, Cur& c2) {
-                if (k2 == "payload") { bytes_array(c2, payload); have_payload = true; }
+                if (k2 == "payload") { once(have_payload); bytes_array(c2, payload); }
                 else skip(c2);
             });
         });
@@ -192,12 +246,12 @@ int32_t shp_tee_decode_request(const uint8_t* json, size_t len, uint32_t height,
         *kind = SHP_TEE_GENERATE_PROOF;
         // Payload { circuit_type, user_public_key, circuit_inputs }
         std::string ctype;
-        bool have_inputs = false, have_key = false;
+        bool have_inputs = false, have_key = false, have_type = false;
         Cur pc{payload.data(), payload.data() + payload.size()};
         object(pc, [&](const std::string& k, Cur& cc) {
-            if (k == "circuit_type") ctype = str(cc);
-            else if (k == "user_public_key") { bytes_array(cc, field); have_key = true; }
-            else if (k == "circuit_inputs") { bytes_array(cc, inner); have_inputs = true; }
+            if (k == "circuit_type") { once(have_type); ctype = str(cc); }
+            else if (k == "user_public_key") { once(have_key); bytes_array(cc, field); }
+            else if (k == "circuit_inputs") { once(have_inputs); bytes_array(cc, inner); }
             else skip(cc);
         });
         end_of_input(pc);
@@ -219,6 +273,7 @@ int32_t shp_tee_decode_request(const uint8_t* json, size_t len, uint32_t height,
             for (int i = 0; i < sh.n_fields; i++)
                 if (k == sh.fields[i]) f = i;
             if (f < 0) { skip(cc); return; }
+            if (seen[f]) bad("duplicate field");
             bytes_array(cc, field);
             const size_t want = f == sh.path_index ? path_bytes : 32;
             if (field.size() != want) bad("circuit_inputs: field of the wrong length");
