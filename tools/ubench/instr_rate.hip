@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <vector>
 #include <string>
+#include <algorithm>
 
 #define REP8(x) x x x x x x x x
 #define REP64(x) REP8(REP8(x))
@@ -69,27 +70,40 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t iters, uint32_t
     out[threadIdx.x + blockIdx.x * blockDim.x] = (uint32_t)(acc0 + acc1 + acc2 + acc3) + x0 + x1 + x2 + x3 + (uint32_t)(d0 + d1 + d2 + d3);
 }
 
+// Each figure is a SLOPE: the kernel is timed at `iters` and at 2 x `iters` loop iterations and the difference is
+// divided by the extra instructions, so launch overhead, the clock ramp after idle and the kernel's prologue cancel.
+// A 50 ms untimed run of the same kernel brings the clocks up first.
 template <int KIND>
 static void run(const char* name, int waves_per_simd, uint32_t* d_out, int cus, double clk_ghz) {
     // blocks of 256 threads = 1 wave per SIMD each
     int blocks = cus * waves_per_simd;
-    uint32_t iters = 2000;
+    const uint32_t iters = 100000;                              // 3.2 M instructions per wave: 5 ms and up per launch
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 10u, 1u);
-    hipDeviceSynchronize();
-    hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1u);
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    double instr_per_wave = (double)iters * 32.0;              // 8 reps x 4 instrs
-    double wave_instr_total = instr_per_wave * blocks * 4.0;   // 4 waves per block
-    double per_simd_per_s = wave_instr_total / (cus * 4.0) / (ms * 1e-3);
-    double cyc_per_instr = clk_ghz * 1e9 / per_simd_per_s;
-    printf("%-28s waves/SIMD=%d  %.3f ms  -> %.2f cycles per wave64-instruction per SIMD (at %.2f GHz)\n", name, waves_per_simd, ms,
-           cyc_per_instr, clk_ghz);
+    auto timed = [&](uint32_t it) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, it, 1u);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        return (double)ms;
+    };
+    double warm = 0;
+    while (warm < 50.0) warm += timed(iters);                   // warm-up: at least 50 ms of this very kernel
+    double t1 = 1e30, t2 = 1e30;
+    for (int rep = 0; rep < 3; rep++) {
+        t1 = std::min(t1, timed(iters));
+        t2 = std::min(t2, timed(2 * iters));
+    }
+    const double instr_per_wave = (double)iters * 32.0;         // 8 reps x 4 instrs per iteration
+    auto cycles = [&](double ms, double n_iters_scale) {
+        double per_simd_per_s = instr_per_wave * n_iters_scale * waves_per_simd / (ms * 1e-3);   // wave-instructions per SIMD per second
+        return clk_ghz * 1e9 / per_simd_per_s;
+    };
+    printf("%-28s waves/SIMD=%d  %.3f ms @%u  %.3f ms @%u  -> slope %.2f cycles per wave64-instruction per SIMD (ratio %.2f; %.2f GHz)\n",
+           name, waves_per_simd, t1, iters, t2, 2 * iters, cycles(t2 - t1, 1.0), cycles(t2, 2.0), clk_ghz);
+    hipEventDestroy(e0); hipEventDestroy(e1);
 }
 
 int main() {
@@ -100,21 +114,17 @@ int main() {
     printf("device %s CUs %d clock %.2f GHz\n", p.name, cus, clk);
     uint32_t* d;
     hipMalloc(&d, (size_t)cus * 8 * 256 * 4);
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 2, 4, 8}) {
         run<0>("v_mad_u64_u32 x4 indep", w, d, cus, clk);
         run<9>("v_mad_u64_u32 dependent", w, d, cus, clk);
-        run<13>("v_mad_u64_u32 rotating add", w, d, cus, clk);
         run<10>("v_mad_u64_u32 + v_addc", w, d, cus, clk);
         run<1>("v_mul_lo_u32", w, d, cus, clk);
-        run<2>("v_mul_hi_u32", w, d, cus, clk);
         run<3>("v_lshl_add_u64", w, d, cus, clk);
         run<4>("v_add_co/addc_co", w, d, cus, clk);
         run<5>("v_mov_b32", w, d, cus, clk);
         run<6>("v_fma_f64", w, d, cus, clk);
-        run<7>("v_mad_u32_u24", w, d, cus, clk);
         run<8>("v_add3_u32", w, d, cus, clk);
         run<11>("v_alignbit_b32", w, d, cus, clk);
-        run<12>("v_lshrrev_b64", w, d, cus, clk);
     }
     return 0;
 }
