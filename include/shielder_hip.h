@@ -165,6 +165,10 @@ int32_t shp_srs_synthetic(shp_ctx* ctx, uint32_t k, const uint8_t tau_le32[32], 
  * generate_keys_with_min_k applies once the circuit's minimal k is known): a NEW SRS with the first
  * 2^k powers, g_lagrange re-derived on the GPU for the smaller domain, the same G2 elements. */
 int32_t shp_srs_downsize(const shp_srs* srs, uint32_t k, shp_srs** out);
+/* marshall_params (/root/reference/crates/shielder_bindings/build.rs:24-29): halo2 RawBytes of the SRS
+ * (k | g | g_lagrange | g2 | s_g2, little-endian Montgomery coordinates) -- byte for byte the layout of the
+ * reference's resources/ppot_0080_11_raw; shp_srs_from_halo2_raw reads it back.  out == NULL only reports the length. */
+int32_t shp_srs_save(const shp_srs* srs, uint8_t* out, size_t out_cap, size_t* out_len);
 int32_t shp_srs_destroy(shp_srs* srs);
 int32_t shp_srs_k(const shp_srs* srs, uint32_t* k);
 /* copies of the tables / G2 elements back to the host (Params::get_g, g2, s_g2) */
@@ -181,11 +185,32 @@ int32_t shp_srs_commit(shp_srs* srs, int32_t basis, const void* d_polys, uint32_
  * outlive the key.  Fixed/permutation polynomials, their extended cosets and commitments are
  * computed on the GPU. */
 int32_t shp_keygen(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan, size_t plan_len, shp_pk** out);
+/* shp_keygen for integrators that hold the halo2 VerifyingKey: `transcript_repr_le32` (32-byte little-endian canonical)
+ * is vk.transcript_repr(), the first word halo2 absorbs into the transcript and the `vk_digest` constant of the generated
+ * verifier (/root/reference/crates/halo2-verifier/src/lib/codegen.rs:162, templates/Halo2Verifier.sol:247-248).  The key then
+ * uses it instead of the library's own digest (Keccak over plan and commitments), so that proofs replay on the
+ * reference's verifiers.  SHP_ERR_FORMAT if >= r. */
+int32_t shp_keygen_with_transcript_repr(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan, size_t plan_len,
+                                        const uint8_t transcript_repr_le32[32], shp_pk** out);
+/* generate_keys_with_min_k(circuit, full_params) -> (params, k, pk, vk)
+ * (/root/reference/crates/shielder_bindings/build.rs:22): finds the smallest k whose usable rows hold the circuit
+ * (shp_plan_min_k), lays the plan out for it, downsizes the SRS (Params::downsize) and generates the key over the
+ * smaller SRS, which the caller owns from then on (*out_srs; it must outlive *out_pk).  transcript_repr_le32 may be NULL. */
+int32_t shp_generate_keys_with_min_k(shp_ctx* ctx, const shp_srs* full_srs, const uint8_t* plan, size_t plan_len,
+                                     const uint8_t* transcript_repr_le32, shp_srs** out_srs, uint32_t* out_k, shp_pk** out_pk);
+/* the smallest k with 2^k - (blinding_factors + 1) rows for everything the plan places on rows (host only) */
+int32_t shp_plan_min_k(const uint8_t* plan, size_t plan_len, uint32_t* k_min);
+/* the same circuit laid out for 2^k rows (k >= shp_plan_min_k; rows keep their index, the permutation mapping is
+ * re-encoded): the plan shp_generate_keys_with_min_k generates its key from.  Host only; out == NULL sizes. */
+int32_t shp_plan_retarget(const uint8_t* plan, size_t plan_len, uint32_t k, uint8_t* out, size_t out_cap, size_t* out_len);
+/* the circuit plan a key was generated from (after any re-layout by shp_generate_keys_with_min_k); out == NULL sizes */
+int32_t shp_pk_plan(const shp_pk* pk, uint8_t* out, size_t out_cap, size_t* out_len);
 int32_t shp_pk_destroy(shp_pk* pk);
 /* marshall_pk / unmarshall_pk (/root/reference/crates/shielder_bindings/build.rs:24-32,
  * src/circuits/mod.rs:38-46).  The saved key is the plan + verifying-key material (commitments, digest):
  * everything else is rebuilt on the GPU at load time in milliseconds, with no MSM.  out == NULL only
- * reports the length.  shp_pk_load fails with SHP_ERR_FORMAT when the digest does not bind the parts. */
+ * reports the length.  The saved key carries a fingerprint of the SRS it was generated over: shp_pk_load fails with
+ * SHP_ERR_FORMAT against any other SRS, and when the stored plan / commitments do not reproduce the stored digest. */
 int32_t shp_pk_save(const shp_pk* pk, uint8_t* out, size_t out_cap, size_t* out_len);
 int32_t shp_pk_load(shp_ctx* ctx, shp_srs* srs, const uint8_t* bytes, size_t len, shp_pk** out);
 int32_t shp_pk_info(const shp_pk* pk, uint32_t* k, uint32_t* n_witness_inputs, uint32_t* n_instances,
@@ -208,6 +233,30 @@ int32_t shp_prover_destroy(shp_prover* p);
 int32_t shp_prove(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, const uint8_t seed[32],
                   uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* instances_le32,
                   size_t instances_cap);
+/* The reference's `rng: &mut impl RngCore` as what it is used for: the Fr::random draws of one proof, pre-drawn by the
+ * caller (`(0..n).map(|_| Fr::random(&mut rng))`), n = shp_pk_randomness_len, Montgomery limbs.  Draw order (halo2
+ * v0.3.0 create_proof): per advice column its blinding_factors+1 last rows (column by column), one unused blind per advice
+ * column; per lookup bf+1 permuted-input rows, bf+1 permuted-table rows, 2 unused blinds; per grand product (permutation
+ * sets, then lookups) bf rows and 1 unused blind; the 2^k coefficients of the random polynomial and 1 unused blind; one
+ * unused blind per quotient piece.  shp_prove's seed is a convenience on top: draw i = from_u512(ChaCha20(seed, block i)),
+ * which shp_blinding_stream writes out (host only), so shp_prove(seed) == shp_prove_with_randomness(stream of seed). */
+int32_t shp_pk_randomness_len(const shp_pk* pk, size_t* n_draws);
+int32_t shp_blinding_stream(const uint8_t seed[32], uint64_t first, size_t count, uint64_t* out_fr);
+int32_t shp_prove_with_randomness(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, const uint64_t* randomness,
+                                  size_t n_draws, uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
+                                  uint8_t* instances_le32, size_t instances_cap);
+/* generate_proof for a circuit the CALLER synthesised: the reference hands create_proof an `impl Circuit<Fr>`
+ * (/root/reference/crates/shielder_bindings/src/circuits/mod.rs:103-111) whose `synthesize` fills the advice columns.  A
+ * Rust integrator runs that synthesis into a collector and passes the result:
+ *   advice         n_columns x n_rows field elements, column-major, Montgomery limbs, host memory; n_columns = the plan's
+ *                  advice columns, n_rows = 2^k.  Rows >= 2^k - (blinding_factors + 1) are ignored (blinded here).
+ *   assigned_rows  rows [assigned_rows, usable) of every column are zero and are not read (0 = all usable rows)
+ *   instances      the public inputs (Montgomery limbs), n_instances = the plan's
+ *   randomness     pre-drawn Fr (see above), or NULL to expand `seed`
+ * The plan's witness program is not run.  Same proof bytes as shp_prove when the columns are the witness program's. */
+int32_t shp_prove_assigned(shp_prover* p, const uint64_t* advice, size_t n_columns, size_t n_rows, size_t assigned_rows,
+                           const uint64_t* instances, size_t n_instances, const uint64_t* randomness, size_t n_draws,
+                           const uint8_t* seed, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
 /* Host threads the lane uses for the witness program (the reference's `synthesize`, rayon in its
  * multithreading feature): the program is cut into independent tasks once per lane (Poseidon2
  * permutations of the Merkle levels run side by side).  Default 8 (env SHP_WITNESS_THREADS); a

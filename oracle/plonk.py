@@ -297,8 +297,10 @@ def _lagrange_column(n, sparse):
     return col
 
 
-def keygen(plan: Plan, srs) -> ProvingKey:
-    """keygen_vk + keygen_pk: fixed/sigma polys, cosets, commitments, l0/l_last/l_active"""
+def keygen(plan: Plan, srs, transcript_repr=None) -> ProvingKey:
+    """keygen_vk + keygen_pk: fixed/sigma polys, cosets, commitments, l0/l_last/l_active.
+    transcript_repr (int): halo2's vk.transcript_repr(), absorbed first by the verifier (Halo2Verifier.sol:247-248), for
+    callers that hold the halo2 VerifyingKey; None = the build's own digest over plan and commitments"""
     assert srs.k == plan.k
     n, k, ek = plan.n, plan.k, plan.ext_k
     pk = ProvingKey()
@@ -337,6 +339,9 @@ def keygen(plan: Plan, srs) -> ProvingKey:
     for c in pk.fixed_commitments + pk.sigma_commitments:
         body += g1_be64(c) if c.any() else bytes(64)
     pk.vk_digest = (int.from_bytes(B.keccak256(body), "big") % R).to_bytes(32, "big")
+    if transcript_repr is not None:
+        assert 0 <= transcript_repr < R
+        pk.vk_digest = int(transcript_repr).to_bytes(32, "big")
     # (zeta * omega_ext^i)^n - 1 has period 2^(ek-k); inverses
     per = 1 << (ek - k)
     zn = pow(pk.zeta, n, R)
@@ -437,9 +442,12 @@ def lagrange_interp(xs, ys):
 
 
 # ------------------------------------------------------------------------------ prover
-def prove(pk: ProvingKey, srs, inputs, seed: bytes, return_trace=False):
+def prove(pk: ProvingKey, srs, inputs, seed: bytes, return_trace=False, randomness=None, assigned=None):
     """create_proof: phases P0..P13. `seed` keys the
-    ChaCha20 blinding stream; draws are consumed in the documented order."""
+    ChaCha20 blinding stream; draws are consumed in the documented order.
+    randomness: (count, 4) Montgomery array of pre-drawn Fr::random values used INSTEAD of the seed's stream (the
+    reference's `rng` handed over as its draws); assigned: (advice_ints[col][row], instances) from the caller's own
+    synthesis instead of the plan's witness program."""
     plan = pk.plan
     n, k, ek, bf, u = plan.n, plan.k, plan.ext_k, plan.bf, plan.usable
     A = plan.num_advice
@@ -448,13 +456,17 @@ def prove(pk: ProvingKey, srs, inputs, seed: bytes, return_trace=False):
     ctr = [0]
 
     def draw(count):
-        out = draws(seed, ctr[0], count)
+        if randomness is not None:
+            out = np.ascontiguousarray(randomness[ctr[0]:ctr[0] + count])
+            assert out.shape[0] == count, "randomness buffer too short"
+        else:
+            out = draws(seed, ctr[0], count)
         ctr[0] += count
         return out
 
     trace = {}
     # P0
-    advice_ints, instances = synthesize(plan, inputs)
+    advice_ints, instances = assigned if assigned is not None else synthesize(plan, inputs)
     tr = Transcript(pk.vk_digest)
     for v in instances:
         tr.common_scalar(v)

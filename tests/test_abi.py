@@ -88,3 +88,33 @@ def test_secret_derivation_reference_kats(shp):
     assert shp.derive_id(16, 26, 45) == before % R != before
     # arbitrary 256-bit inputs are accepted (U256, not a field element)
     assert 0 <= shp.derive_id(2**256 - 1, 2**64 - 1, 2**32 - 1) < R
+
+
+def test_plan_min_k_and_relayout_on_the_host():
+    """shp_plan_min_k / shp_plan_retarget (no GPU): a circuit laid out for 2^11 rows that fits 2^9 is found to need k = 9, and
+    its re-layout IS the plan the builder emits for k = 9, byte for byte (and back)"""
+    import importlib
+    shp = importlib.import_module("zkos-monorepo_amd")
+    C = importlib.import_module("zkos-monorepo_amd.circuits")
+    kw = dict(height=1, range_bits=4, range_chunks=8)
+    p11, _ = C.build_withdraw_plan(k=11, **kw)
+    p9, _ = C.build_withdraw_plan(k=9, **kw)
+    assert shp.plan_min_k(p11) == 9 and shp.plan_min_k(p9) == 9
+    assert shp.plan_retarget(p11, 9) == p9 and shp.plan_retarget(p9, 11) == p11 and shp.plan_retarget(p9, 9) == p9
+    with pytest.raises(shp.ShpError) as e:
+        shp.plan_retarget(p11, 8)
+    assert e.value.code == shp.SHP_ERR_INVALID_ARG
+    with pytest.raises(shp.ShpError) as e:
+        shp.plan_min_k(p11[:-1])
+    assert e.value.code == shp.SHP_ERR_FORMAT
+
+
+def test_blinding_stream_is_chacha20_wide_reduction(oracle):
+    """shp_blinding_stream (host): draw i = from_u512(ChaCha20(seed, block i)), the oracle's stream"""
+    import importlib
+    import numpy as np
+    shp = importlib.import_module("zkos-monorepo_amd")
+    PL = importlib.import_module("oracle.plonk")
+    seed = bytes(range(32))
+    assert np.array_equal(shp.blinding_stream(seed, 0, 300), PL.draws(seed, 0, 300))
+    assert np.array_equal(shp.blinding_stream(seed, 2**33 + 5, 3), PL.draws(seed, 2**33 + 5, 3))

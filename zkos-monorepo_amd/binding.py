@@ -105,9 +105,12 @@ def to_host(t):
 class Context:
     """One per (process, GPU): shp_ctx."""
 
+    created = 0          # contexts made by this process: once > 0 the process has initialised the GPU
+
     def __init__(self, device=0):
         self.h = C.c_void_p()
         _check(lib().shp_ctx_create(C.c_int32(device), C.byref(self.h)))
+        Context.created += 1
         self.device = device
         # torch is plumbing only: make the context's HIP stream torch's current stream, so that
         # torch copies, torch.cuda.Event timing and the library's kernels are ordered on ONE stream
@@ -256,6 +259,14 @@ class Params:
         _check(lib().shp_srs_get_g(self.h, C.c_int32(basis), out.ctypes.data_as(C.c_void_p), C.c_size_t(self.n)))
         return out
 
+    def save_raw(self) -> bytes:
+        """marshall_params: halo2 RawBytes (k | g | g_lagrange | g2 | s_g2), what read_raw reads"""
+        n = C.c_size_t()
+        _check(lib().shp_srs_save(self.h, None, C.c_size_t(0), C.byref(n)))
+        out = C.create_string_buffer(n.value)
+        _check(lib().shp_srs_save(self.h, out, C.c_size_t(n.value), C.byref(n)))
+        return out.raw[:n.value]
+
     def g2(self):
         a, b = C.create_string_buffer(128), C.create_string_buffer(128)
         _check(lib().shp_srs_get_g2(self.h, a, b))
@@ -284,36 +295,75 @@ def poseidon2_hash_host(ints):
     return int.from_bytes(out.raw, "little")
 
 
+def blinding_stream(seed: bytes, first: int, count: int):
+    """the Fr draws shp_prove(seed) consumes: draw i = from_u512(ChaCha20(seed, block i)); (count, 4) Montgomery limbs"""
+    out = np.zeros((count, 4), dtype=np.uint64)
+    _check(lib().shp_blinding_stream(C.c_char_p(seed), C.c_uint64(first), C.c_size_t(count), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def plan_min_k(plan: bytes) -> int:
+    k = C.c_uint32()
+    _check(lib().shp_plan_min_k(C.c_char_p(plan), C.c_size_t(len(plan)), C.byref(k)))
+    return k.value
+
+
+def plan_retarget(plan: bytes, k: int) -> bytes:
+    n = C.c_size_t()
+    _check(lib().shp_plan_retarget(C.c_char_p(plan), C.c_size_t(len(plan)), C.c_uint32(k), None, C.c_size_t(0), C.byref(n)))
+    out = C.create_string_buffer(n.value)
+    _check(lib().shp_plan_retarget(C.c_char_p(plan), C.c_size_t(len(plan)), C.c_uint32(k), out, C.c_size_t(n.value), C.byref(n)))
+    return out.raw[:n.value]
+
+
 class ProvingKey:
     """Device-resident proving key of one circuit plan (the reference's `ProvingKey` + vk)."""
 
-    def __init__(self, ctx: Context, params: Params, plan: bytes = None, saved: bytes = None):
-        """generate_keys_with_min_k (plan given) or unmarshall_pk (saved = bytes of save())"""
+    def __init__(self, ctx: Context, params: Params, plan: bytes = None, saved: bytes = None, transcript_repr: int = None,
+                 handle=None):
+        """keygen (plan given; transcript_repr = halo2's vk.transcript_repr() when the caller has it) or unmarshall_pk
+        (saved = bytes of save())"""
         self.ctx, self.params = ctx, params
         self.h = C.c_void_p()
-        if saved is not None:
+        if handle is not None:
+            self.h = handle
+        elif saved is not None:
             _check(lib().shp_pk_load(ctx.h, params.h, C.c_char_p(saved), C.c_size_t(len(saved)), C.byref(self.h)))
+        elif transcript_repr is not None:
+            _check(lib().shp_keygen_with_transcript_repr(ctx.h, params.h, C.c_char_p(plan), C.c_size_t(len(plan)),
+                                                         C.c_char_p(int(transcript_repr).to_bytes(32, "little")), C.byref(self.h)))
         else:
             _check(lib().shp_keygen(ctx.h, params.h, C.c_char_p(plan), C.c_size_t(len(plan)), C.byref(self.h)))
         k, ni, nins, pl = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         _check(lib().shp_pk_info(self.h, C.byref(k), C.byref(ni), C.byref(nins), C.byref(pl)))
         self.k, self.n_inputs, self.n_instances, self.proof_len = k.value, ni.value, nins.value, pl.value
+        nd = C.c_size_t()
+        _check(lib().shp_pk_randomness_len(self.h, C.byref(nd)))
+        self.n_draws = nd.value
 
     @classmethod
     def load(cls, ctx, params, saved: bytes):
         return cls(ctx, params, saved=saved)
 
     @classmethod
-    def generate_keys_with_min_k(cls, ctx, full_params: Params, plan: bytes):
+    def generate_keys_with_min_k(cls, ctx, full_params: Params, plan: bytes, transcript_repr: int = None):
         """generate_keys_with_min_k(circuit, full_params) -> (params, k, pk)
-        (call site /root/reference/crates/shielder_bindings/build.rs:22-31): the plan states the circuit's k;
-        the full SRS is downsized to it (Params::downsize) and the keys are generated over the result."""
-        import struct
-        if len(plan) < 12 or plan[:4] != b"SHPL":
-            raise ShpError(SHP_ERR_FORMAT, "generate_keys_with_min_k: not a circuit plan")
-        k = struct.unpack_from("<I", plan, 8)[0]
-        params = full_params if full_params.k == k else full_params.downsize(k)
-        return params, k, cls(ctx, params, plan)
+        (call site /root/reference/crates/shielder_bindings/build.rs:22-31), in the library: the smallest k that holds the
+        circuit, the plan laid out for it, the SRS downsized (Params::downsize), the keys generated over the result."""
+        hs, hp, k = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        tr = C.c_char_p(int(transcript_repr).to_bytes(32, "little")) if transcript_repr is not None else None
+        _check(lib().shp_generate_keys_with_min_k(ctx.h, full_params.h, C.c_char_p(plan), C.c_size_t(len(plan)), tr,
+                                                  C.byref(hs), C.byref(k), C.byref(hp)))
+        params = Params(ctx, hs)
+        return params, k.value, cls(ctx, params, handle=hp)
+
+    def plan(self) -> bytes:
+        """the circuit plan the key was generated from (re-laid-out by generate_keys_with_min_k)"""
+        n = C.c_size_t()
+        _check(lib().shp_pk_plan(self.h, None, C.c_size_t(0), C.byref(n)))
+        out = C.create_string_buffer(n.value)
+        _check(lib().shp_pk_plan(self.h, out, C.c_size_t(n.value), C.byref(n)))
+        return out.raw[:n.value]
 
     def save(self) -> bytes:
         """marshall_pk: plan + verifying-key material (the rest is rebuilt on the GPU at load time)"""
@@ -377,6 +427,35 @@ class Prover:
                                C.c_size_t(self.pk.proof_len), C.byref(plen), inst, C.c_size_t(len(inst.raw))))
         ins = [int.from_bytes(inst.raw[32 * i:32 * i + 32], "little") for i in range(self.pk.n_instances)]
         return proof.raw[:plen.value], ins
+
+    def prove_with_randomness(self, witness_ints, draws):
+        """generate_proof with the caller's pre-drawn Fr::random values: draws = (pk.n_draws, 4) uint64 Montgomery limbs"""
+        wit = b"".join(int(x).to_bytes(32, "little") for x in witness_ints)
+        d = np.ascontiguousarray(draws, dtype=np.uint64)
+        proof = C.create_string_buffer(self.pk.proof_len)
+        plen = C.c_size_t()
+        inst = C.create_string_buffer(max(1, 32 * self.pk.n_instances))
+        _check(lib().shp_prove_with_randomness(self.h, C.c_char_p(wit), C.c_size_t(len(wit) // 32), d.ctypes.data_as(C.c_void_p),
+                                               C.c_size_t(d.shape[0]), proof, C.c_size_t(self.pk.proof_len), C.byref(plen), inst,
+                                               C.c_size_t(len(inst.raw))))
+        ins = [int.from_bytes(inst.raw[32 * i:32 * i + 32], "little") for i in range(self.pk.n_instances)]
+        return proof.raw[:plen.value], ins
+
+    def prove_assigned(self, advice, instances, assigned_rows=0, seed: bytes = None, draws=None):
+        """generate_proof for caller-synthesised advice columns: advice = (A, n, 4) uint64 Montgomery limbs, instances =
+        (n_instances, 4); randomness = `draws` ((pk.n_draws, 4) Montgomery) or a 32-byte `seed`"""
+        adv = np.ascontiguousarray(advice, dtype=np.uint64)
+        ins = np.ascontiguousarray(instances, dtype=np.uint64).reshape(-1, 4)
+        d = None if draws is None else np.ascontiguousarray(draws, dtype=np.uint64)
+        proof = C.create_string_buffer(self.pk.proof_len)
+        plen = C.c_size_t()
+        _check(lib().shp_prove_assigned(self.h, adv.ctypes.data_as(C.c_void_p), C.c_size_t(adv.shape[0]), C.c_size_t(adv.shape[1]),
+                                        C.c_size_t(assigned_rows), ins.ctypes.data_as(C.c_void_p), C.c_size_t(ins.shape[0]),
+                                        d.ctypes.data_as(C.c_void_p) if d is not None else None,
+                                        C.c_size_t(d.shape[0] if d is not None else 0),
+                                        C.c_char_p(seed) if seed is not None else None, proof, C.c_size_t(self.pk.proof_len),
+                                        C.byref(plen)))
+        return proof.raw[:plen.value]
 
     def mode(self, throughput: bool):
         """shp_prover_mode: latency (default) or throughput scheduling of this lane"""

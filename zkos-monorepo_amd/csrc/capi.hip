@@ -106,6 +106,17 @@ static bool on_curve(const G1Affine& p) {
 using namespace shp;
 
 static void srs_finish(shp_srs* s) {
+    {
+        std::vector<uint8_t> m(4 + 3 * sizeof(G1Affine) + 256, 0);
+        memcpy(m.data(), &s->k, 4);
+        SHP_HIP(hipMemcpy(m.data() + 4, s->d_g, (s->n >= 2 ? 2 : 1) * sizeof(G1Affine), hipMemcpyDeviceToHost));
+        SHP_HIP(hipMemcpy(m.data() + 4 + 2 * sizeof(G1Affine), s->d_gl, sizeof(G1Affine), hipMemcpyDeviceToHost));
+        if (s->has_g2) {
+            memcpy(m.data() + 4 + 3 * sizeof(G1Affine), s->g2, 128);
+            memcpy(m.data() + 4 + 3 * sizeof(G1Affine) + 128, s->s_g2, 128);
+        }
+        keccak256(m.data(), m.size(), s->fingerprint);
+    }
     int32_t rc = shp_msm_create_dev(s->ctx, s->d_g, s->n, 0, &s->msm_g);
     SHP_REQUIRE(rc == SHP_OK, rc, std::string("srs: msm plan over g: ") + shp_last_error());
     rc = shp_msm_create_dev(s->ctx, s->d_gl, s->n, 0, &s->msm_gl);
@@ -119,6 +130,16 @@ static void srs_release(shp_srs* s) {
     if (s->d_g) (void)hipFree(s->d_g);
     if (s->d_gl) (void)hipFree(s->d_gl);
     delete s;
+}
+
+// canonical little-endian Fq2 coordinates -> the Montgomery form the files hold
+static void g2_to_montgomery(const uint8_t* src_canon, uint8_t* dst) {
+    for (int c = 0; c < 4; c++) {
+        Fq raw;
+        memcpy(raw.l, src_canon + 32 * c, 32);
+        Fq m = Fq::from_raw(raw);
+        memcpy(dst + 32 * c, m.l, 32);
+    }
 }
 
 // stored Montgomery Fq2 coordinates -> canonical little-endian bytes
@@ -509,6 +530,25 @@ int32_t shp_srs_from_halo2_raw(shp_ctx* ctx, const uint8_t* b, size_t len, shp_s
         g2_to_canonical(b + 4 + 2 * n * 64 + 128, s_g2);
         int32_t rc = shp_srs_from_parts(ctx, k, g.data(), gl.data(), g2, s_g2, out);
         SHP_REQUIRE(rc == SHP_OK, rc, shp_last_error());
+    });
+}
+
+// marshall_params (/root/reference/crates/shielder_bindings/build.rs:24-29): halo2's RawBytes form of ParamsKZG,
+// k | g | g_lagrange | g2 | s_g2 with every coordinate in little-endian Montgomery form -- the layout of the
+// reference's resources/ppot_0080_11_raw, which shp_srs_from_halo2_raw reads back
+int32_t shp_srs_save(const shp_srs* srs, uint8_t* out, size_t out_cap, size_t* out_len) {
+    return guarded([&] {
+        SHP_REQUIRE(srs && out_len, SHP_ERR_INVALID_ARG, "srs_save: null argument");
+        SHP_REQUIRE(srs->has_g2, SHP_ERR_INVALID_ARG, "srs_save: this SRS carries no G2 elements");
+        const size_t tab = srs->n * sizeof(G1Affine), total = 4 + 2 * tab + 256;
+        *out_len = total;
+        if (!out) return;
+        SHP_REQUIRE(out_cap >= total, SHP_ERR_INVALID_ARG, "srs_save: buffer too small");
+        memcpy(out, &srs->k, 4);
+        SHP_HIP(hipMemcpy(out + 4, srs->d_g, tab, hipMemcpyDeviceToHost));
+        SHP_HIP(hipMemcpy(out + 4 + tab, srs->d_gl, tab, hipMemcpyDeviceToHost));
+        g2_to_montgomery(srs->g2, out + 4 + 2 * tab);
+        g2_to_montgomery(srs->s_g2, out + 4 + 2 * tab + 128);
     });
 }
 

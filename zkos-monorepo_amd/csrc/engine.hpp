@@ -110,6 +110,7 @@ struct shp_srs {
     shp_msm* msm_gl = nullptr;
     uint8_t g2[128] = {0}, s_g2[128] = {0};
     bool has_g2 = false;
+    uint8_t fingerprint[32] = {0};        // Keccak over k, g[0], g[1], g_lagrange[0], g2, s_g2: what a saved key is bound to
 };
 
 // one entry of a multi-job direct-table launch: `batch` MSMs over m's bases, scalar column b at scalars + b * stride

@@ -5,6 +5,7 @@
 #pragma once
 #include <string.h>
 
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -51,6 +52,13 @@ struct PlanData {
     }
 
     void parse(const uint8_t* d, size_t len);
+    // the plan's bytes again (parse(serialize()) is the identity on everything parse reads)
+    std::vector<uint8_t> serialize() const;
+    // generate_keys_with_min_k (/root/reference/crates/shielder_bindings/build.rs:22): the smallest k whose usable rows
+    // (2^k - (bf + 1)) hold everything the plan places on rows -- fixed values, copy constraints, witness cells, public
+    // inputs -- and the same plan laid out for another k (rows keep their index, the permutation mapping is re-encoded)
+    uint32_t min_k() const;
+    PlanData retarget(uint32_t new_k) const;
 };
 
 inline void PlanData::parse(const uint8_t* d, size_t len) {
@@ -191,6 +199,80 @@ inline void PlanData::parse(const uint8_t* d, size_t len) {
     chunk = degree - 2;
     num_sets = npc ? (npc + chunk - 1) / chunk : 0;
     rot_last = -(int32_t)(bf + 1);
+}
+
+inline std::vector<uint8_t> PlanData::serialize() const {
+    std::vector<uint8_t> out;
+    auto put = [&](const void* p, size_t bytes) {
+        const uint8_t* b = static_cast<const uint8_t*>(p);
+        out.insert(out.end(), b, b + bytes);
+    };
+    auto put_fr = [&](const Fr& v) {
+        const Fr raw = v.to_raw();
+        put(raw.l, 32);
+    };
+    const uint32_t h[20] = {1, k, num_advice, num_fixed, num_instance, bf, degree, (uint32_t)adv_q.size(), (uint32_t)fix_q.size(),
+                            (uint32_t)inst_q.size(), (uint32_t)perm_cols.size(), (uint32_t)consts.size(), (uint32_t)gate_prog.size(),
+                            gate_slots, num_gates, (uint32_t)lookups.size(), n_winputs, (uint32_t)wops.size(), n_wscratch,
+                            (uint32_t)instance_map.size()};
+    put("SHPL", 4);
+    put(h, 80);
+    for (const auto* qs : {&adv_q, &fix_q, &inst_q})
+        for (const Query& q : *qs) { put(&q.col, 4); put(&q.rot, 4); }
+    for (const auto& pc : perm_cols) { put(&pc.first, 4); put(&pc.second, 4); }
+    for (const Fr& c : consts) put_fr(c);
+    if (!gate_prog.empty()) put(gate_prog.data(), gate_prog.size() * sizeof(Instr));
+    for (const LookupPlan& lk : lookups) {
+        const uint32_t hh[5] = {lk.m, (uint32_t)lk.in_prog.size(), lk.in_slots, (uint32_t)lk.tab_prog.size(), lk.tab_slots};
+        put(hh, 20);
+        if (!lk.in_prog.empty()) put(lk.in_prog.data(), lk.in_prog.size() * sizeof(Instr));
+        if (!lk.tab_prog.empty()) put(lk.tab_prog.data(), lk.tab_prog.size() * sizeof(Instr));
+    }
+    for (const auto& col : fixed) {
+        const uint32_t nnz = (uint32_t)col.size();
+        put(&nnz, 4);
+        for (const auto& e : col) { put(&e.first, 4); put_fr(e.second); }
+    }
+    for (const auto& m : mapping) put(m.data(), m.size() * 4);
+    if (!wops.empty()) put(wops.data(), wops.size() * sizeof(WOp));
+    for (const auto& im : instance_map) { put(&im.first, 4); put(&im.second, 4); }
+    return out;
+}
+
+inline uint32_t PlanData::min_k() const {
+    uint32_t rows = 1;                                           // rows in use: highest row index + 1
+    for (const auto& col : fixed)
+        for (const auto& e : col) rows = std::max(rows, e.first + 1);
+    for (size_t c = 0; c < mapping.size(); c++)
+        for (uint32_t r = 0; r < n; r++)
+            if (mapping[c][r] != (uint32_t)(c * n + r)) rows = std::max(rows, r + 1);
+    for (const WOp& w : wops)
+        if (w.dc < num_advice) rows = std::max(rows, w.dr + 1);
+    for (const auto& im : instance_map) rows = std::max(rows, im.second + 1);
+    rows = std::max(rows, num_instance);
+    uint32_t kk = 4;                                             // the smallest k a plan may have
+    while ((1ull << kk) < (uint64_t)rows + bf + 1 || (1u << kk) < 64) kk++;
+    return std::min(kk, k);
+}
+
+inline PlanData PlanData::retarget(uint32_t new_k) const {
+    SHP_REQUIRE(new_k >= min_k() && new_k <= 20, SHP_ERR_INVALID_ARG, "plan: the circuit does not fit the requested k");
+    PlanData q = *this;
+    q.k = new_k;
+    const uint32_t nn = 1u << new_k;
+    for (size_t c = 0; c < mapping.size(); c++) {
+        q.mapping[c].assign(nn, 0);
+        for (uint32_t r = 0; r < nn; r++) {
+            const uint32_t tgt = r < n ? mapping[c][r] : (uint32_t)(c * n + r);
+            const uint32_t tc = r < n ? tgt / n : (uint32_t)c, tr = r < n ? tgt % n : r;
+            SHP_REQUIRE(tr < nn, SHP_ERR_INTERNAL, "plan: permutation target beyond the new domain");
+            q.mapping[c][r] = tc * nn + tr;
+        }
+    }
+    const std::vector<uint8_t> bytes = q.serialize();            // derived fields (n, usable, ext_k ...) through parse
+    PlanData out;
+    out.parse(bytes.data(), bytes.size());
+    return out;
 }
 
 }  // namespace shp

@@ -95,6 +95,7 @@ struct shp_pk {
     // host copies
     std::vector<G1Affine> fixed_comm, sigma_comm;
     uint8_t vk_digest[32];
+    bool digest_injected = false;                  // vk_digest = the caller's transcript_repr, not the library's own
     std::vector<uint8_t> plan_bytes;               // the circuit plan the key was generated from (shp_pk_save)
     Fr omega, omega_inv, delta, zeta;
     std::vector<Fr> delta_pow;
@@ -139,8 +140,11 @@ static void launch_prog(hipStream_t st, const ProgArgs& a, uint32_t size, bool t
 }
 
 // stored_comm: commitments read from a saved key (fixed then sigma); nullptr = compute them (MSMs)
+// transcript_repr_le32 (optional): the first word of the transcript, 32-byte little-endian canonical -- halo2's
+// vk.transcript_repr() (absorbed at /root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:247-248, emitted at
+// src/lib/codegen.rs:162) for callers that hold the halo2 VerifyingKey; nullptr = the library's own digest.
 static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, size_t len, shp_pk** out,
-                        const std::vector<G1Affine>* stored_comm = nullptr) {
+                        const std::vector<G1Affine>* stored_comm = nullptr, const uint8_t* transcript_repr_le32 = nullptr) {
     SHP_REQUIRE(ctx && srs && plan_bytes && out, SHP_ERR_INVALID_ARG, "keygen: null argument");
     SHP_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<shp_pk> pk(new shp_pk);
@@ -315,6 +319,13 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
         raw.l[i] = ((uint32_t)h[31 - 4 * i]) | ((uint32_t)h[30 - 4 * i] << 8) | ((uint32_t)h[29 - 4 * i] << 16) |
                    ((uint32_t)h[28 - 4 * i] << 24);
     to_be32(Fr::from_raw(raw), pk->vk_digest);
+    if (transcript_repr_le32) {
+        Fr t;
+        memcpy(t.l, transcript_repr_le32, 32);
+        SHP_REQUIRE(!t.geq_p(), SHP_ERR_FORMAT, "keygen: transcript_repr is not a canonical field element");
+        to_be32(Fr::from_raw(t), pk->vk_digest);
+        pk->digest_injected = true;
+    }
     build_rotation_sets(P, pk->rot_superset, pk->rot_sets);
     SHP_REQUIRE(pk->rot_superset.size() <= MAX_POINTS && pk->rot_sets.size() <= MAX_SETS, SHP_ERR_INVALID_ARG,
                 "keygen: too many rotation sets");
@@ -589,6 +600,13 @@ struct shp_prover {
     Fr *blinds = nullptr, *ntt_tmp = nullptr;
     uint32_t* key = nullptr;
     Fr* h_grid = nullptr;                                      // pinned host staging of the witness grid
+    // The grid and the device columns are cleared once; the witness program rewrites the same cells every proof.  A proof
+    // from caller-assigned columns (shp_prove_assigned) writes other cells: grid_foreign makes the next witness-program
+    // proof clear the grid first, dev_rows (leading rows of the device columns that may be non-zero) lets every proof
+    // clear what the previous one left beyond its own rows.
+    bool grid_foreign = false;
+    uint32_t dev_rows = 0;
+    PinnedBuf h_rand;                                          // caller-supplied coefficients of the random polynomial
     WitnessSchedule wsched;                                    // witness program cut into parallel tasks
     std::unique_ptr<WitnessWorkers> wworkers;
     std::vector<Fr> wscratch;                                  // scratch row of the sequential path
@@ -625,6 +643,7 @@ struct shp_prover {
     ~shp_prover() {
         if (comb_event) (void)hipEventDestroy(comb_event);
         stage.release();
+        h_rand.release();
         for (void* p : owned) (void)hipFree(p);
         msm_ws.release();
         if (h_grid) (void)hipHostFree(h_grid);
@@ -763,8 +782,33 @@ struct PhaseClock {
 }  // namespace
 
 // ------------------------------------------------------------------------------ create_proof
-static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inputs, const uint8_t seed[32],
-                       std::vector<uint8_t>& proof_out, std::vector<Fr>& instances_out) {
+// What a proof is made from.  Witness: either the plan's witness-program inputs (32-byte LE canonical each), or the advice
+// columns a caller synthesised itself (the reference runs the circuit's `synthesize`) plus the public inputs.
+// Randomness (the reference's `rng`): either a 32-byte seed expanded with ChaCha20, or the draws themselves.
+struct ProveInput {
+    const uint8_t* inputs_le32 = nullptr;    // witness program: n_inputs x 32 bytes
+    size_t n_inputs = 0;
+    const Fr* advice = nullptr;              // assigned columns: [A][n] Montgomery, host memory
+    uint32_t assigned_rows = 0;              //   rows [assigned_rows, usable) of every column are zero and not read
+    const Fr* instances = nullptr;           //   public inputs, Montgomery
+    size_t n_instances = 0;
+    const uint8_t* seed = nullptr;           // 32 bytes, or
+    const Fr* draws = nullptr;               // n_draws field elements in draw order (Montgomery)
+    size_t n_draws = 0;
+};
+
+// Fr::random draws one proof consumes, in this order: per advice column its bf+1 blinding rows (column-major), A unused
+// commitment blinds; per lookup bf+1 permuted-input rows, bf+1 permuted-table rows, 2 unused blinds; per grand product
+// (permutation sets, then lookups) bf rows + 1 unused blind; the n coefficients of the random polynomial + 1 unused blind;
+// one unused blind per quotient piece.
+static uint64_t randomness_len(const PlanData& P) {
+    const uint64_t A = P.num_advice, L = P.lookups.size(), S = P.num_sets, nb = P.bf + 1;
+    return A * nb + A + L * (2 * nb + 2) + (S + L) * (P.bf + 1) + P.n + 1 + (P.degree - 1);
+}
+
+static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t>& proof_out, std::vector<Fr>& instances_out) {
+    const uint8_t* const inputs_le32 = in.inputs_le32;
+    const size_t n_inputs = in.n_inputs;
     shp_pk* pk = pr->pk;
     shp_ctx* ctx = pk->ctx;
     shp_srs* srs = pk->srs;
@@ -775,7 +819,20 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     const uint32_t A = P.num_advice, L = (uint32_t)P.lookups.size(), S = P.num_sets, NV = pk->NV;
     const uint32_t PC = (uint32_t)P.perm_cols.size(), F = P.num_fixed;
     const uint32_t nb = bf + 1;
-    SHP_REQUIRE(n_inputs == P.n_winputs, SHP_ERR_INVALID_ARG, "prove: wrong number of witness inputs");
+    const bool assigned = in.advice != nullptr;
+    if (assigned) {
+        SHP_REQUIRE(in.assigned_rows <= u, SHP_ERR_INVALID_ARG, "prove_assigned: more assigned rows than usable rows");
+        SHP_REQUIRE(in.n_instances == P.num_instance && (in.instances || !in.n_instances), SHP_ERR_INVALID_ARG,
+                    "prove_assigned: wrong number of public inputs");
+    } else {
+        SHP_REQUIRE(inputs_le32 && n_inputs == P.n_winputs, SHP_ERR_INVALID_ARG, "prove: wrong number of witness inputs");
+    }
+    SHP_REQUIRE((in.seed != nullptr) != (in.draws != nullptr), SHP_ERR_INVALID_ARG, "prove: pass a seed or a randomness buffer");
+    if (in.draws) {
+        SHP_REQUIRE(in.n_draws == randomness_len(P), SHP_ERR_INVALID_ARG, "prove: randomness buffer of the wrong length (shp_pk_randomness_len)");
+        for (size_t i = 0; i < in.n_draws; i++)
+            SHP_REQUIRE(!in.draws[i].geq_p(), SHP_ERR_FORMAT, "prove: randomness buffer holds a non-canonical field element");
+    }
     const uint32_t I_PIN = A, I_PZ = A + 2 * L, I_LZ = A + 2 * L + S, I_INST = NV;
     auto V = [&](uint32_t idx) { return pr->vals + (size_t)idx * n; };
     auto PL = [&](uint32_t idx) { return pr->polys + (size_t)idx * n; };
@@ -813,10 +870,10 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         pr->timers.end(st);
     };
 
-    uint32_t key[8];
-    memcpy(key, seed, 32);
+    uint32_t key[8] = {0};
+    if (in.seed) memcpy(key, in.seed, 32);
     uint64_t ctr = 0;
-    auto draw = [&]() { return fr_draw(key, ctr++); };
+    auto draw = [&]() { return in.draws ? in.draws[ctr++] : fr_draw(key, ctr++); };
 
     PhaseClock pc(pr->keep_phases ? &pr->last_phases : nullptr);
     pr->stage_off = 0;                                  // the previous proof's copies have all completed
@@ -843,22 +900,45 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
         }
     };
     // ---- P0/P1: witness, blinding rows, instance column
-    std::vector<Fr> inputs(n_inputs);
-    for (size_t i = 0; i < n_inputs; i++) {
-        Fr raw;
-        memcpy(raw.l, inputs_le32 + 32 * i, 32);
-        SHP_REQUIRE(!raw.geq_p(), SHP_ERR_FORMAT, "prove: witness input is not a canonical field element");
-        inputs[i] = Fr::from_raw(raw);
-    }
     std::vector<Fr> instances;
     Fr* const grid = pr->h_grid;                        // pinned: [A][n] advice, then the instance column
-    // no per-proof clearing: the program writes the same cells every time (fixed plan), the blinding rows are
-    // redrawn below, everything else has been zero since prover_create
-    if (pr->wworkers) pr->wworkers->run(P, inputs, grid, pr->wsched);
-    else run_witness_range(P, inputs, grid, pr->wscratch.data(), 0, (uint32_t)P.wops.size());
-    instances.resize(P.instance_map.size());
-    for (size_t i = 0; i < instances.size(); i++)
-        instances[i] = grid[(size_t)P.instance_map[i].first * n + P.instance_map[i].second];
+    uint32_t rows_now;                                  // leading rows of the advice columns that this proof may fill
+    if (assigned) {
+        // the caller's columns: rows [0, assigned_rows) through the pinned grid (asynchronous copies from pageable memory
+        // serialise the streams of concurrent lanes), values validated on the way
+        rows_now = in.assigned_rows ? in.assigned_rows : u;
+        for (uint32_t c = 0; c < A; c++) {
+            const Fr* src = in.advice + (size_t)c * n;
+            Fr* dst = grid + (size_t)c * n;
+            for (uint32_t r = 0; r < rows_now; r++) {
+                SHP_REQUIRE(!src[r].geq_p(), SHP_ERR_FORMAT, "prove_assigned: advice value is not a canonical field element");
+                dst[r] = src[r];
+            }
+        }
+        pr->grid_foreign = true;
+        instances.assign(in.instances, in.instances + in.n_instances);
+        for (auto& v : instances) SHP_REQUIRE(!v.geq_p(), SHP_ERR_FORMAT, "prove_assigned: public input is not a canonical field element");
+    } else {
+        std::vector<Fr> inputs(n_inputs);
+        for (size_t i = 0; i < n_inputs; i++) {
+            Fr raw;
+            memcpy(raw.l, inputs_le32 + 32 * i, 32);
+            SHP_REQUIRE(!raw.geq_p(), SHP_ERR_FORMAT, "prove: witness input is not a canonical field element");
+            inputs[i] = Fr::from_raw(raw);
+        }
+        if (pr->grid_foreign) {                         // an assigned-columns proof left other cells behind
+            memset(grid, 0, (size_t)A * n * sizeof(Fr));
+            pr->grid_foreign = false;
+        }
+        // no per-proof clearing: the program writes the same cells every time (fixed plan), the blinding rows are
+        // redrawn below, everything else has been zero since prover_create
+        if (pr->wworkers) pr->wworkers->run(P, inputs, grid, pr->wsched);
+        else run_witness_range(P, inputs, grid, pr->wscratch.data(), 0, (uint32_t)P.wops.size());
+        instances.resize(P.instance_map.size());
+        for (size_t i = 0; i < instances.size(); i++)
+            instances[i] = grid[(size_t)P.instance_map[i].first * n + P.instance_map[i].second];
+        rows_now = P.adv_rows;
+    }
     pc.mark("run_witness");
     for (uint32_t c = 0; c < A; c++)
         for (uint32_t r = u; r < n; r++) grid[(size_t)c * n + r] = draw();
@@ -866,10 +946,14 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     ctr += A;                                           // one (unused) commitment blind per advice column
     Fr* const instcol = grid + (size_t)A * n;           // rows past the instances stay zero (cleared at creation)
     for (size_t i = 0; i < instances.size(); i++) instcol[i] = instances[i];
-    // only the rows the witness program assigns and the blinding rows travel; the rest is zero on both sides
+    // only the rows this proof assigns and the blinding rows travel; the rest is zero on both sides
     const size_t pitch = (size_t)n * sizeof(Fr);
-    if (A && P.adv_rows)
-        SHP_HIP(hipMemcpy2DAsync(V(0), pitch, grid, pitch, (size_t)P.adv_rows * sizeof(Fr), A, hipMemcpyHostToDevice, st));
+    if (A && rows_now < pr->dev_rows)                   // the previous proof filled more rows than this one
+        hipLaunchKernelGGL(zero_rows_kernel, dim3(ceil_div(pr->dev_rows - rows_now, 256), A), dim3(256), 0, st, V(0), (size_t)n,
+                           rows_now, pr->dev_rows);
+    pr->dev_rows = rows_now;
+    if (A && rows_now)
+        SHP_HIP(hipMemcpy2DAsync(V(0), pitch, grid, pitch, (size_t)rows_now * sizeof(Fr), A, hipMemcpyHostToDevice, st));
     if (A) SHP_HIP(hipMemcpy2DAsync(V(0) + u, pitch, grid + u, pitch, (size_t)(n - u) * sizeof(Fr), A, hipMemcpyHostToDevice, st));
     if (!instances.empty())
         SHP_HIP(hipMemcpyAsync(V(I_INST), instcol, instances.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
@@ -880,9 +964,15 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     // ---- P2: advice commitments.  The random polynomial of P7 depends on no challenge: its
     // coefficients (blinding stream position known up front) and its commitment ride in the same launch.
     const uint64_t ctr_rand = (uint64_t)A * nb + A + (uint64_t)L * (2 * nb + 2) + (uint64_t)(S + L) * (bf + 1);
-    hipLaunchKernelGGL(chacha_fr_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->key, ctr_rand, n, pr->rand_poly);
+    if (in.draws) {
+        pr->h_rand.reserve((size_t)n * sizeof(Fr));
+        memcpy(pr->h_rand.p, in.draws + ctr_rand, (size_t)n * sizeof(Fr));
+        SHP_HIP(hipMemcpyAsync(pr->rand_poly, pr->h_rand.p, (size_t)n * sizeof(Fr), hipMemcpyHostToDevice, st));
+    } else {
+        hipLaunchKernelGGL(chacha_fr_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->key, ctr_rand, n, pr->rand_poly);
+    }
     std::vector<G1Affine> pts(std::max<uint32_t>({A + 1, 2 * L, S + L + 1, P.degree}));
-    const MsmRows adv_rows{P.adv_rows, u, n - u};     // assigned rows + blinding rows; the rest is zero
+    const MsmRows adv_rows{rows_now, u, n - u};       // assigned rows + blinding rows; the rest is zero
     commit(srs->msm_gl, V(0), A, pts.data(), &adv_rows, srs->msm_g, pr->rand_poly, 1);
     const G1Affine rand_comm = pts[A];
     for (uint32_t c = 0; c < A; c++) tr.write_point(pts[c].x, pts[c].y);
@@ -1044,6 +1134,7 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
                        pk->nc, n, hp);
     const uint32_t npieces = P.degree - 1;
     ctr += npieces;                                      // one (unused) blind per quotient piece
+    SHP_REQUIRE(ctr == randomness_len(P), SHP_ERR_INTERNAL, "prove: blinding stream length");
     commit(srs->msm_g, hp, npieces, pts.data());
     for (uint32_t i = 0; i < npieces; i++) tr.write_point(pts[i].x, pts[i].y);
     pc.mark("quotient_msm");
@@ -1208,6 +1299,8 @@ static void prove_impl(shp_prover* pr, const uint8_t* inputs_le32, size_t n_inpu
     (void)F;
 }
 
+int shp_pk_device(const shp_pk* pk) { return pk->ctx->device; }
+
 void shp_pk_vk_view(const shp_pk* pk, VkView& out) {
     out.plan = &pk->plan;
     out.vk_digest = pk->vk_digest;
@@ -1234,26 +1327,111 @@ int32_t shp_keygen(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan, size_t plan_
     return guarded([&] { keygen_impl(ctx, srs, plan, plan_len, out); });
 }
 
+int32_t shp_keygen_with_transcript_repr(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan, size_t plan_len,
+                                        const uint8_t transcript_repr_le32[32], shp_pk** out) {
+    return guarded([&] { keygen_impl(ctx, srs, plan, plan_len, out, nullptr, transcript_repr_le32); });
+}
+
+int32_t shp_plan_min_k(const uint8_t* plan, size_t plan_len, uint32_t* k_min) {
+    return guarded([&] {
+        SHP_REQUIRE(plan && k_min, SHP_ERR_INVALID_ARG, "plan_min_k: null argument");
+        PlanData P;
+        P.parse(plan, plan_len);
+        *k_min = P.min_k();
+    });
+}
+
+int32_t shp_plan_retarget(const uint8_t* plan, size_t plan_len, uint32_t k, uint8_t* out, size_t out_cap, size_t* out_len) {
+    return guarded([&] {
+        SHP_REQUIRE(plan && out_len, SHP_ERR_INVALID_ARG, "plan_retarget: null argument");
+        PlanData P;
+        P.parse(plan, plan_len);
+        const std::vector<uint8_t> bytes = P.retarget(k).serialize();
+        *out_len = bytes.size();
+        if (!out) return;
+        SHP_REQUIRE(out_cap >= bytes.size(), SHP_ERR_INVALID_ARG, "plan_retarget: buffer too small");
+        memcpy(out, bytes.data(), bytes.size());
+    });
+}
+
+int32_t shp_generate_keys_with_min_k(shp_ctx* ctx, const shp_srs* full_srs, const uint8_t* plan, size_t plan_len,
+                                     const uint8_t* transcript_repr_le32, shp_srs** out_srs, uint32_t* out_k, shp_pk** out_pk) {
+    return guarded([&] {
+        SHP_REQUIRE(ctx && full_srs && plan && out_srs && out_pk, SHP_ERR_INVALID_ARG, "generate_keys_with_min_k: null argument");
+        PlanData P;
+        P.parse(plan, plan_len);
+        const uint32_t kk = P.min_k();
+        SHP_REQUIRE(kk <= full_srs->k, SHP_ERR_INVALID_ARG, "generate_keys_with_min_k: the circuit needs more rows than the SRS has powers");
+        std::vector<uint8_t> bytes(plan, plan + plan_len);
+        if (kk != P.k) bytes = P.retarget(kk).serialize();
+        shp_srs* small = nullptr;
+        int32_t rc = shp_srs_downsize(full_srs, kk, &small);
+        SHP_REQUIRE(rc == SHP_OK, rc, std::string("generate_keys_with_min_k: ") + shp_last_error());
+        try {
+            keygen_impl(ctx, small, bytes.data(), bytes.size(), out_pk, nullptr, transcript_repr_le32);
+        } catch (...) {
+            (void)shp_srs_destroy(small);
+            throw;
+        }
+        *out_srs = small;
+        if (out_k) *out_k = kk;
+    });
+}
+
+int32_t shp_pk_plan(const shp_pk* pk, uint8_t* out, size_t out_cap, size_t* out_len) {
+    return guarded([&] {
+        SHP_REQUIRE(pk && out_len, SHP_ERR_INVALID_ARG, "pk_plan: null argument");
+        *out_len = pk->plan_bytes.size();
+        if (!out) return;
+        SHP_REQUIRE(out_cap >= pk->plan_bytes.size(), SHP_ERR_INVALID_ARG, "pk_plan: buffer too small");
+        memcpy(out, pk->plan_bytes.data(), pk->plan_bytes.size());
+    });
+}
+
+int32_t shp_pk_randomness_len(const shp_pk* pk, size_t* n_draws) {
+    return guarded([&] {
+        SHP_REQUIRE(pk && n_draws, SHP_ERR_INVALID_ARG, "pk_randomness_len: null argument");
+        *n_draws = (size_t)randomness_len(pk->plan);
+    });
+}
+
+int32_t shp_blinding_stream(const uint8_t seed[32], uint64_t first, size_t count, uint64_t* out_fr) {
+    return guarded([&] {
+        SHP_REQUIRE(seed && (out_fr || !count), SHP_ERR_INVALID_ARG, "blinding_stream: null argument");
+        uint32_t key[8];
+        memcpy(key, seed, 32);
+        for (size_t i = 0; i < count; i++) {
+            const Fr v = fr_draw(key, first + i);
+            memcpy(out_fr + 4 * i, v.l, 32);
+        }
+    });
+}
+
 // ---- marshall_pk / unmarshall_pk (/root/reference/crates/shielder_bindings/build.rs:24-32,
 // src/circuits/mod.rs:38-46).  Everything in the key except the commitments is a cheap, deterministic
 // GPU function of (plan, SRS) -- keygen without the MSMs is a few NTTs -- so the saved key is the
 // plan plus the verifying-key material, not tens of MB of polynomials; loading rebuilds the device
 // resident tables in milliseconds (the TEE decodes its pk.bin on every request, server.rs:170-173).
-//   "SHPK0001" | u32 k | u32 plan_len | plan | u32 F | u32 PC | F+PC x 64 B commitments | 32 B vk digest
-static const char PK_MAGIC[8] = {'S', 'H', 'P', 'K', '0', '0', '0', '1'};
+//   "SHPK0002" | u32 k | u32 flags | 32 B SRS fingerprint | u32 plan_len | plan | u32 F | u32 PC |
+//   F+PC x 64 B commitments | 32 B vk digest
+// flags bit 0: the digest is a caller-supplied transcript_repr (shp_keygen_with_transcript_repr), not the library's own.
+// The SRS fingerprint (Keccak over k, g[0], g[1], g_lagrange[0], g2, s_g2) binds the key to the SRS its commitments were
+// computed over: loading it against another SRS of the same k fails instead of yielding proofs that never verify.
+static const char PK_MAGIC[8] = {'S', 'H', 'P', 'K', '0', '0', '0', '2'};
 
 int32_t shp_pk_save(const shp_pk* pk, uint8_t* out, size_t out_cap, size_t* out_len) {
     return guarded([&] {
         SHP_REQUIRE(pk && out_len, SHP_ERR_INVALID_ARG, "pk_save: null argument");
         const uint32_t F = (uint32_t)pk->fixed_comm.size(), PC = (uint32_t)pk->sigma_comm.size();
-        const size_t total = 8 + 4 + 4 + pk->plan_bytes.size() + 4 + 4 + (size_t)(F + PC) * sizeof(G1Affine) + 32;
+        const size_t total = 8 + 4 + 4 + 32 + 4 + pk->plan_bytes.size() + 4 + 4 + (size_t)(F + PC) * sizeof(G1Affine) + 32;
         *out_len = total;
         if (!out) return;
         SHP_REQUIRE(out_cap >= total, SHP_ERR_INVALID_ARG, "pk_save: buffer too small");
         uint8_t* p = out;
         auto put = [&](const void* src, size_t n) { memcpy(p, src, n); p += n; };
-        const uint32_t k = pk->plan.k, pl = (uint32_t)pk->plan_bytes.size();
-        put(PK_MAGIC, 8); put(&k, 4); put(&pl, 4); put(pk->plan_bytes.data(), pl); put(&F, 4); put(&PC, 4);
+        const uint32_t k = pk->plan.k, pl = (uint32_t)pk->plan_bytes.size(), flags = pk->digest_injected ? 1u : 0u;
+        put(PK_MAGIC, 8); put(&k, 4); put(&flags, 4); put(pk->srs->fingerprint, 32);
+        put(&pl, 4); put(pk->plan_bytes.data(), pl); put(&F, 4); put(&PC, 4);
         put(pk->fixed_comm.data(), (size_t)F * sizeof(G1Affine));
         put(pk->sigma_comm.data(), (size_t)PC * sizeof(G1Affine));
         put(pk->vk_digest, 32);
@@ -1266,11 +1444,15 @@ int32_t shp_pk_load(shp_ctx* ctx, shp_srs* srs, const uint8_t* bytes, size_t len
         const uint8_t* p = bytes;
         const uint8_t* end = bytes + len;
         auto need = [&](size_t n) { SHP_REQUIRE((size_t)(end - p) >= n, SHP_ERR_FORMAT, "pk_load: truncated key"); };
-        need(16);
+        need(52);
         SHP_REQUIRE(memcmp(p, PK_MAGIC, 8) == 0, SHP_ERR_FORMAT, "pk_load: bad magic / version");
-        uint32_t k, pl, F, PC;
-        memcpy(&k, p + 8, 4); memcpy(&pl, p + 12, 4);
-        p += 16;
+        uint32_t k, flags, pl, F, PC;
+        memcpy(&k, p + 8, 4); memcpy(&flags, p + 12, 4);
+        SHP_REQUIRE(flags <= 1, SHP_ERR_FORMAT, "pk_load: unknown flags");
+        SHP_REQUIRE(memcmp(p + 16, srs->fingerprint, 32) == 0, SHP_ERR_FORMAT,
+                    "pk_load: the key was generated over a different SRS");
+        memcpy(&pl, p + 48, 4);
+        p += 52;
         need(pl);
         const uint8_t* plan = p;
         p += pl;
@@ -1283,11 +1465,15 @@ int32_t shp_pk_load(shp_ctx* ctx, shp_srs* srs, const uint8_t* bytes, size_t len
         memcpy(comm.data(), p, comm.size() * sizeof(G1Affine));
         p += comm.size() * sizeof(G1Affine);
         SHP_REQUIRE(p + 32 == end, SHP_ERR_FORMAT, "pk_load: trailing bytes");
+        uint8_t repr_le[32];
+        for (int i = 0; i < 32; i++) repr_le[i] = p[31 - i];       // the digest is stored big-endian, as absorbed
         shp_pk* pk = nullptr;
-        keygen_impl(ctx, srs, plan, pl, &pk, &comm);
+        keygen_impl(ctx, srs, plan, pl, &pk, &comm, (flags & 1) ? repr_le : nullptr);
         std::unique_ptr<shp_pk> guard(pk);
         SHP_REQUIRE(pk->plan.k == k, SHP_ERR_FORMAT, "pk_load: k differs from the plan");
-        // the digest binds plan and commitments: a key whose parts were altered does not load
+        // The library's own digest is recomputed from the stored plan and commitments: accidental corruption of either
+        // does not load.  (It does not prove that the commitments ARE the plan's: that would take the MSMs the saved
+        // form exists to avoid; a key file is trusted input, like the reference's pk.bin.)
         SHP_REQUIRE(memcmp(pk->vk_digest, p, 32) == 0, SHP_ERR_FORMAT, "pk_load: verifying-key digest mismatch");
         *out = guard.release();
     });
@@ -1421,23 +1607,68 @@ int32_t shp_prover_destroy(shp_prover* p) {
     return guarded([&] { delete p; });
 }
 
+static void proof_out_copy(const std::vector<uint8_t>& proof, const std::vector<Fr>& inst, uint8_t* proof_out, size_t proof_cap,
+                           size_t* proof_len, uint8_t* instances_le32, size_t instances_cap) {
+    SHP_REQUIRE(proof.size() <= proof_cap, SHP_ERR_INVALID_ARG, "prove: proof buffer too small");
+    memcpy(proof_out, proof.data(), proof.size());
+    *proof_len = proof.size();
+    if (instances_le32) {
+        SHP_REQUIRE(inst.size() * 32 <= instances_cap, SHP_ERR_INVALID_ARG, "prove: instance buffer too small");
+        for (size_t i = 0; i < inst.size(); i++) {
+            Fr raw = inst[i].to_raw();
+            memcpy(instances_le32 + 32 * i, raw.l, 32);
+        }
+    }
+}
+
 int32_t shp_prove(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, const uint8_t seed[32], uint8_t* proof_out,
                   size_t proof_cap, size_t* proof_len, uint8_t* instances_le32, size_t instances_cap) {
     return guarded([&] {
         SHP_REQUIRE(p && witness_le32 && seed && proof_out && proof_len, SHP_ERR_INVALID_ARG, "prove: null argument");
         std::vector<uint8_t> proof;
         std::vector<Fr> inst;
-        prove_impl(p, witness_le32, n_inputs, seed, proof, inst);
-        SHP_REQUIRE(proof.size() <= proof_cap, SHP_ERR_INVALID_ARG, "prove: proof buffer too small");
-        memcpy(proof_out, proof.data(), proof.size());
-        *proof_len = proof.size();
-        if (instances_le32) {
-            SHP_REQUIRE(inst.size() * 32 <= instances_cap, SHP_ERR_INVALID_ARG, "prove: instance buffer too small");
-            for (size_t i = 0; i < inst.size(); i++) {
-                Fr raw = inst[i].to_raw();
-                memcpy(instances_le32 + 32 * i, raw.l, 32);
-            }
-        }
+        ProveInput in;
+        in.inputs_le32 = witness_le32; in.n_inputs = n_inputs; in.seed = seed;
+        prove_impl(p, in, proof, inst);
+        proof_out_copy(proof, inst, proof_out, proof_cap, proof_len, instances_le32, instances_cap);
+    });
+}
+
+int32_t shp_prove_with_randomness(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, const uint64_t* randomness,
+                                  size_t n_draws, uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
+                                  uint8_t* instances_le32, size_t instances_cap) {
+    return guarded([&] {
+        SHP_REQUIRE(p && witness_le32 && randomness && proof_out && proof_len, SHP_ERR_INVALID_ARG, "prove_with_randomness: null argument");
+        std::vector<uint8_t> proof;
+        std::vector<Fr> inst;
+        ProveInput in;
+        in.inputs_le32 = witness_le32; in.n_inputs = n_inputs;
+        in.draws = reinterpret_cast<const Fr*>(randomness); in.n_draws = n_draws;
+        prove_impl(p, in, proof, inst);
+        proof_out_copy(proof, inst, proof_out, proof_cap, proof_len, instances_le32, instances_cap);
+    });
+}
+
+int32_t shp_prove_assigned(shp_prover* p, const uint64_t* advice, size_t n_columns, size_t n_rows, size_t assigned_rows,
+                           const uint64_t* instances, size_t n_instances, const uint64_t* randomness, size_t n_draws,
+                           const uint8_t* seed, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+    return guarded([&] {
+        SHP_REQUIRE(p && advice && proof_out && proof_len, SHP_ERR_INVALID_ARG, "prove_assigned: null argument");
+        const PlanData& P = p->pk->plan;
+        SHP_REQUIRE(n_columns == P.num_advice && n_rows == P.n, SHP_ERR_INVALID_ARG,
+                    "prove_assigned: the advice block must be num_advice columns of 2^k rows");
+        SHP_REQUIRE(assigned_rows <= P.usable, SHP_ERR_INVALID_ARG, "prove_assigned: more assigned rows than usable rows");
+        std::vector<uint8_t> proof;
+        std::vector<Fr> inst;
+        ProveInput in;
+        in.advice = reinterpret_cast<const Fr*>(advice);
+        in.assigned_rows = (uint32_t)assigned_rows;
+        in.instances = reinterpret_cast<const Fr*>(instances);
+        in.n_instances = n_instances;
+        if (randomness) { in.draws = reinterpret_cast<const Fr*>(randomness); in.n_draws = n_draws; }
+        else in.seed = seed;
+        prove_impl(p, in, proof, inst);
+        proof_out_copy(proof, inst, proof_out, proof_cap, proof_len, nullptr, 0);
     });
 }
 

@@ -164,6 +164,12 @@ __global__ __launch_bounds__(PROG_THREADS) void prog_fold_reg_kernel(ProgArgs a)
     st(a.out + row, acc);
 }
 
+// rows [r0, r1) of every column (blockIdx.y) to zero: what a previous proof assigned beyond this proof's rows
+__global__ void zero_rows_kernel(Fr* cols, size_t stride, uint32_t r0, uint32_t r1) {
+    const uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < r1) st(cols + (size_t)blockIdx.y * stride + r, Fr::zero());
+}
+
 // ------------------------------------------------------------------ blinding stream
 __global__ void chacha_fr_kernel(const uint32_t* key8, uint64_t counter0, uint32_t count, Fr* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
