@@ -280,6 +280,13 @@ int32_t shp_public_inputs(const shp_pk* pk, const uint8_t* witness_le32, size_t 
  * *accepted = 1 / 0; the status is an error only for unusable arguments (e.g. an SRS without G2). */
 int32_t shp_verify(const shp_pk* pk, const uint8_t* proof, size_t proof_len, const uint8_t* instances_le32,
                    size_t n_instances, int32_t* accepted);
+/* shp_verify that also reports what the reference's generated contract keeps in its named memory words
+ * (/root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:39-73), as 22 big-endian 32-byte words in this order:
+ * theta, beta, gamma, y, x, zeta, nu, mu, x^n, (x^n - 1)^-1, l_last, l_blind, l_0, instance_eval, quotient_eval,
+ * quotient commitment x, y, g1 scalar (= -r_eval), pairing lhs x, y, pairing rhs x, y.  Words the run did not reach
+ * (a malformed proof is refused early) stay zero.  For cross-checks against the contract's own run. */
+int32_t shp_verify_trace(const shp_pk* pk, const uint8_t* proof, size_t proof_len, const uint8_t* instances_le32,
+                         size_t n_instances, int32_t* accepted, uint8_t* words_be32, size_t words_cap);
 /* HIP-event timing of the lane's kernel launches, on the stream they run on: enable (resets the
  * counters), prove, then read entry `index` (0 .. until SHP_ERR_INVALID_ARG): kernel family name,
  * number of launches, summed duration. */

@@ -740,10 +740,14 @@ def proof_layout(plan):
     return n_points, n_evals, 64 * n_points + 32 * n_evals + 128
 
 
-def verify(pk: ProvingKey, proof: bytes, instances, tau=None, g2=None, s_g2=None):
+def verify(pk: ProvingKey, proof: bytes, instances, tau=None, g2=None, s_g2=None, trace=None):
     """verify_proof restated from Halo2Verifier.sol + codegen.  The final
     check e(lhs, g2) = e(W', s g2) is done with the trapdoor when `tau` is known (synthetic SRS)
-    or with the BN254 pairing (oracle/pairing.py) when g2 / s_g2 are given."""
+    or with the BN254 pairing (oracle/pairing.py) when g2 / s_g2 are given.
+    trace (dict, optional): receives what the reference's contract keeps in its named memory words
+    (Halo2Verifier.sol:39-73) -- challenges, x^n, Lagrange values, instance / quotient evaluations, quotient
+    commitment, pairing inputs -- as ints, keyed by the contract's constant names; pinned against the contract's own
+    run by tests/golden/verifier_trace.json."""
     plan = pk.plan
     n = plan.n
     L, S = len(plan.lookups), plan.num_sets
@@ -856,10 +860,17 @@ def verify(pk: ProvingKey, proof: bytes, instances, tau=None, g2=None, s_g2=None
         numer = (numer * y + l_act * (a_ - s_) * (a_ - ap)) % R
     h_eval = numer * pow((xn - 1) % R, -1, R) % R
     evals[(("h",), 0)] = h_eval
+    if trace is not None:
+        trace.update(THETA_MPTR=theta, BETA_MPTR=beta, GAMMA_MPTR=gamma, Y_MPTR=y, X_MPTR=x, ZETA_MPTR=zeta_c, NU_MPTR=nu,
+                     MU_MPTR=mu, X_N_MPTR=xn, X_N_MINUS_1_INV_MPTR=pow((xn - 1) % R, -1, R), L_LAST_MPTR=l_last,
+                     L_BLIND_MPTR=l_blind, L_0_MPTR=l_0, INSTANCE_EVAL_MPTR=inst_eval, QUOTIENT_EVAL_MPTR=h_eval)
     # commitment to h: sum_i x^(n i) H_i
     h_comm = None
     for c in reversed(h_c):
         h_comm = c if h_comm is None else B.g1_add(B.g1_mul(h_comm, fe(xn)), c)
+    if trace is not None:
+        hx_, hy_ = B.g1_affine_ints(h_comm.reshape(1, 8))[0]
+        trace.update(QUOTIENT_X_MPTR=hx_, QUOTIENT_Y_MPTR=hy_)
     comms = {("h",): h_comm, ("rand",): rand_c}
     for c in range(plan.num_advice): comms[("adv", c)] = adv_c[c]
     for c in range(plan.num_fixed): comms[("fix", c)] = pk.fixed_commitments[c]
@@ -908,6 +919,11 @@ def verify(pk: ProvingKey, proof: bytes, instances, tau=None, g2=None, s_g2=None
     lhs = B.g1_add(acc_pt, B.g1_mul(G, fe((-r_total) % R)))
     lhs = B.g1_add(lhs, B.g1_mul(W, fe((-z0v) % R)))
     lhs = B.g1_add(lhs, B.g1_mul(Wp, fe(mu)))
+    if trace is not None:
+        lx_, ly_ = B.g1_affine_ints(lhs.reshape(1, 8))[0]
+        rx_, ry_ = B.g1_affine_ints(Wp.reshape(1, 8))[0]
+        trace.update(G1_SCALAR_MPTR=(-r_total) % R, PAIRING_LHS_X_MPTR=lx_, PAIRING_LHS_Y_MPTR=ly_, PAIRING_RHS_X_MPTR=rx_,
+                     PAIRING_RHS_Y_MPTR=ry_)
     if tau is not None:
         return bool(np.array_equal(lhs, B.g1_mul(Wp, fe(tau))))
     from . import pairing

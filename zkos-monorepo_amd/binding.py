@@ -388,6 +388,15 @@ class ProvingKey:
                                 C.byref(ok)))
         return bool(ok.value)
 
+    def verify_trace(self, proof: bytes, instances):
+        """shp_verify_trace: (accepted, [22 ints]) -- the words the reference's contract keeps (Halo2Verifier.sol:39-73)"""
+        ins = b"".join(int(x).to_bytes(32, "little") for x in instances)
+        ok = C.c_int32(0)
+        words = C.create_string_buffer(22 * 32)
+        _check(lib().shp_verify_trace(self.h, C.c_char_p(proof), C.c_size_t(len(proof)), C.c_char_p(ins), C.c_size_t(len(instances)),
+                                      C.byref(ok), words, C.c_size_t(22 * 32)))
+        return bool(ok.value), [int.from_bytes(words.raw[32 * i:32 * i + 32], "big") for i in range(22)]
+
     def vk_digest(self) -> bytes:
         out = C.create_string_buffer(32)
         _check(lib().shp_pk_vk_digest(self.h, out))

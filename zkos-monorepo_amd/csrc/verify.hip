@@ -430,7 +430,19 @@ std::vector<Fr> run_program_scalar(const std::vector<Instr>& prog, uint32_t nslo
 
 }  // namespace
 
-static bool verify_impl(const VkView& vk, const uint8_t* proof, size_t proof_len, const uint8_t* inst_le32, size_t n_inst) {
+// `trace` (optional): the values the reference's contract keeps in its named memory words (Halo2Verifier.sol:39-73), in the
+// order of shp_verify_trace, as 32-byte big-endian words; filled as far as the run gets
+static bool verify_impl(const VkView& vk, const uint8_t* proof, size_t proof_len, const uint8_t* inst_le32, size_t n_inst,
+                        std::vector<uint8_t>* trace = nullptr) {
+    auto tput_fr = [&](size_t slot, const Fr& v) {
+        if (trace) to_be32(v, trace->data() + 32 * slot);
+    };
+    auto tput_pt = [&](size_t slot, const G1Affine& p) {
+        if (!trace) return;
+        if (p.is_inf()) { memset(trace->data() + 32 * slot, 0, 64); return; }
+        to_be32(p.x, trace->data() + 32 * slot);
+        to_be32(p.y, trace->data() + 32 * slot + 32);
+    };
     const PlanData& P = *vk.plan;
     const uint32_t n = P.n, L = (uint32_t)P.lookups.size(), S = P.num_sets, PC = (uint32_t)P.perm_cols.size();
     const uint32_t A = P.num_advice;
@@ -562,6 +574,15 @@ static bool verify_impl(const VkView& vk, const uint8_t* proof, size_t proof_len
     }
     if ((xn - one).is_zero()) return false;
     ev[{7, 0, 0}] = numer * Fr::inv(xn - one);        // h(x)
+    if (trace) {
+        const Fr words[15] = {theta, beta, gamma, y, x, zeta_c, nu, mu, xn, Fr::inv(xn - one), l_last, l_blind, l_0, inst_eval,
+                              ev.at({7, 0, 0})};
+        for (size_t i = 0; i < 15; i++) tput_fr(i, words[i]);
+        std::vector<Fr> pw(h_c.size());                  // the quotient commitment sum_i x^(n i) H_i (Halo2Verifier.sol:494-512)
+        Fr p = one;
+        for (auto& v : pw) { v = p; p = p * xn; }
+        tput_pt(15, g1_to_affine(g1_msm_host(h_c, pw)));
+    }
     // Every group element of the check enters ONE multi-scalar multiplication: terms (point, scalar) are collected
     // while the scalars are worked out in the field.  The commitment to h is sum_i x^(n i) H_i, so a term s * [h]
     // expands into the pieces with scalars s * x^(n i).
@@ -643,6 +664,9 @@ static bool verify_impl(const VkView& vk, const uint8_t* proof, size_t proof_len
     clock_gettime(CLOCK_MONOTONIC, &ta);
     const G1X lhs = g1_msm_host(term_pts, term_scs);
     clock_gettime(CLOCK_MONOTONIC, &tb);
+    tput_fr(17, Fr::neg(r_total));
+    tput_pt(18, g1_to_affine(lhs));
+    tput_pt(20, Wp);
     // e(lhs, g2) e(W', -s g2) = 1   (Halo2Verifier.sol:553-559)
     SHP_REQUIRE(vk.has_g2, SHP_ERR_INVALID_ARG, "verify: the SRS of this key carries no G2 part");
     const G2A g2 = g2_from_bytes(vk.g2);
@@ -667,6 +691,20 @@ void shp_synthetic_g2(const Fr& tau_mont, uint8_t g2_out[128], uint8_t s_g2_out[
     g.y = PC_().g2y;
     g2_to_bytes(g, g2_out);
     g2_to_bytes(g2_mul(g, tau_mont.to_raw()), s_g2_out);
+}
+
+extern "C" int32_t shp_verify_trace(const shp_pk* pk, const uint8_t* proof, size_t proof_len, const uint8_t* instances_le32,
+                                    size_t n_instances, int32_t* accepted, uint8_t* words_be32, size_t words_cap) {
+    return guarded([&] {
+        SHP_REQUIRE(pk && proof && accepted && words_be32 && (instances_le32 || n_instances == 0), SHP_ERR_INVALID_ARG,
+                    "verify_trace: null argument");
+        SHP_REQUIRE(words_cap >= 22 * 32, SHP_ERR_INVALID_ARG, "verify_trace: 22 words of 32 bytes are written");
+        VkView vk;
+        shp_pk_vk_view(pk, vk);
+        std::vector<uint8_t> tr(22 * 32, 0);
+        *accepted = verify_impl(vk, proof, proof_len, instances_le32, n_instances, &tr) ? 1 : 0;
+        memcpy(words_be32, tr.data(), tr.size());
+    });
 }
 
 extern "C" int32_t shp_verify(const shp_pk* pk, const uint8_t* proof, size_t proof_len, const uint8_t* instances_le32,
