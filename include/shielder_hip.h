@@ -198,6 +198,16 @@ int32_t shp_keygen_with_transcript_repr(shp_ctx* ctx, shp_srs* srs, const uint8_
  * smaller SRS, which the caller owns from then on (*out_srs; it must outlive *out_pk).  transcript_repr_le32 may be NULL. */
 int32_t shp_generate_keys_with_min_k(shp_ctx* ctx, const shp_srs* full_srs, const uint8_t* plan, size_t plan_len,
                                      const uint8_t* transcript_repr_le32, shp_srs** out_srs, uint32_t* out_k, shp_pk** out_pk);
+/* The compile step of the plan emitter (the role of the circuit crates at build time,
+ * /root/reference/crates/shielder_bindings/build.rs:19-32): a CIRCUIT DESCRIPTION -- what a host reads off a halo2
+ * ConstraintSystem and a keygen-time synthesis, the quantities of
+ * /root/reference/crates/halo2-verifier/src/lib/codegen/util.rs:42-131: queries in the constraint system's order,
+ * permutation columns, gate and lookup expressions as nodes, fixed values, copy constraints or the finished permutation
+ * mapping, optionally a witness program -- becomes the circuit plan shp_keygen takes: degree and blinding factors,
+ * merged subexpressions, the interpreter programs with their slot allocation, the permutation mapping.  Byte layout of
+ * the description: zkos-monorepo_amd/csrc/plancompile.hip; a Rust emitter for it: INTEGRATION.md.  Host only;
+ * out == NULL sizes. */
+int32_t shp_plan_compile(const uint8_t* description, size_t len, uint8_t* out, size_t out_cap, size_t* out_len);
 /* the smallest k with 2^k - (blinding_factors + 1) rows for everything the plan places on rows (host only) */
 int32_t shp_plan_min_k(const uint8_t* plan, size_t plan_len, uint32_t* k_min);
 /* the same circuit laid out for 2^k rows (k >= shp_plan_min_k; rows keep their index, the permutation mapping is

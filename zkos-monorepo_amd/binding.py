@@ -308,6 +308,15 @@ def plan_min_k(plan: bytes) -> int:
     return k.value
 
 
+def plan_compile(description: bytes) -> bytes:
+    """shp_plan_compile: circuit description (PlanBuilder.build_description) -> circuit plan"""
+    n = C.c_size_t()
+    _check(lib().shp_plan_compile(C.c_char_p(description), C.c_size_t(len(description)), None, C.c_size_t(0), C.byref(n)))
+    out = C.create_string_buffer(n.value)
+    _check(lib().shp_plan_compile(C.c_char_p(description), C.c_size_t(len(description)), out, C.c_size_t(n.value), C.byref(n)))
+    return out.raw[:n.value]
+
+
 def plan_retarget(plan: bytes, k: int) -> bytes:
     n = C.c_size_t()
     _check(lib().shp_plan_retarget(C.c_char_p(plan), C.c_size_t(len(plan)), C.c_uint32(k), None, C.c_size_t(0), C.byref(n)))

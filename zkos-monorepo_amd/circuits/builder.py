@@ -235,6 +235,81 @@ class PlanBuilder:
             per_col[c] = per_col.get(c, 0) + 1
         return max(3, max(per_col.values(), default=1)) + 2
 
+    # ---- the circuit description the library compiles itself (shp_plan_compile, csrc/plancompile.hip)
+    def build_description(self):
+        """What a host holding a halo2 ConstraintSystem would emit: queries, permutation columns, expressions as nodes,
+        fixed values, copy constraints, witness program -- no compiled programs, no degree, no mapping."""
+        self.build()                                   # registers every query and constant (idempotent)
+        nodes, ids = [], {}
+        KIND = {"const": 0, "adv": 1, "fix": 2, "inst": 3, "add": 4, "sub": 5, "mul": 6, "neg": 7}
+
+        def node(e):
+            k = id(e)
+            if k in ids:
+                return ids[k]
+            stack = [(e, False)]
+            while stack:                               # iterative post-order: children before parents
+                cur, done = stack.pop()
+                if id(cur) in ids:
+                    continue
+                kids = [a for a in cur.args if isinstance(a, Expr)]
+                if not done and kids:
+                    stack.append((cur, True))
+                    stack.extend((a, False) for a in reversed(kids))
+                    continue
+                if cur.kind == "const": rec = (0, self.const_index(cur.args[0]), 0)
+                elif cur.kind == "adv": rec = (1, self.adv_query(*cur.args), 0)
+                elif cur.kind == "fix": rec = (2, self.fix_query(*cur.args), 0)
+                elif cur.kind == "inst": rec = (3, self.inst_query(*cur.args), 0)
+                elif cur.kind == "neg": rec = (7, ids[id(kids[0])], 0)
+                else: rec = (KIND[cur.kind], ids[id(kids[0])], ids[id(kids[1])])
+                ids[id(cur)] = len(nodes)
+                nodes.append(rec)
+            return ids[k]
+
+        gates = [node(g) for g in self.gates]
+        lookups = [([node(e) for e in ins], [node(e) for e in tabs]) for ins, tabs in self.lookups]
+        scratch_col = self.num_advice
+        cell = lambda c: (scratch_col, c[1]) if c[0] == "S" else c
+        wops = []
+        for op, dc, dr, ac, ar, bc, br, imm in self.wops:
+            d, a, b_ = cell((dc, dr)), cell((ac, ar)), cell((bc, br))
+            wops.append((op, d[0], d[1], a[0], a[1], b_[0], b_[1], imm))
+        hdr = [1, self.k, self.num_advice, self.num_fixed, self.num_instance, len(self.adv_q), len(self.fix_q), len(self.inst_q),
+               len(self.perm_cols), len(self.consts), len(nodes), len(gates), len(lookups), len(self.copies), 0,
+               self.n_winputs, len(wops), self.n_wscratch, len(self.instance_map), 0]
+        out = bytearray(b"SHCD" + struct.pack("<20I", *hdr))
+        for lst in (self.adv_q, self.fix_q, self.inst_q):
+            for c, r in lst:
+                out += struct.pack("<Ii", c, r)
+        for t, i in self.perm_cols:
+            out += struct.pack("<II", t, i)
+        for v in self.consts:
+            out += v.to_bytes(32, "little")
+        for rec in nodes:
+            out += struct.pack("<3I", *rec)
+        for g in gates:
+            out += struct.pack("<I", g)
+        for ins, tabs in lookups:
+            out += struct.pack("<I", len(ins))
+            for v in ins + tabs:
+                out += struct.pack("<I", v)
+        per_col = [[] for _ in range(self.num_fixed)]
+        for (c, r), v in sorted(self.fixed_vals.items()):
+            if v:
+                per_col[c].append((r, v))
+        for lst in per_col:
+            out += struct.pack("<I", len(lst))
+            for r, v in lst:
+                out += struct.pack("<I", r) + v.to_bytes(32, "little")
+        for (ta, ia, ra), (tb, ib, rb) in self.copies:
+            out += struct.pack("<6I", ta, ia, ra, tb, ib, rb)
+        for ins in wops:
+            out += struct.pack("<8I", *ins)
+        for c, r in self.instance_map:
+            out += struct.pack("<II", c, r)
+        return bytes(out)
+
     # ---- serialisation
     def build(self):
         n = self.n

@@ -85,13 +85,13 @@ def _external(s):
     return [x[i] + w[i] for i in range(4)] + [x[i + 4] + w[i] for i in range(4)]
 
 
-def build_deposit_plan(k=13, height=13, range_bits=12, range_chunks=10):
+def build_deposit_plan(k=13, height=13, range_bits=12, range_chunks=10, describe=False):
     """Deposit-shaped stand-in (DepositProverKnowledge, crates/shielder_bindings/src/circuits/deposit.rs:88-114):
     the withdraw relation with balance_new = balance_old + value and the Deposit instance / argument order."""
-    return build_withdraw_plan(k, height, range_bits, range_chunks, kind="deposit")
+    return build_withdraw_plan(k, height, range_bits, range_chunks, kind="deposit", describe=describe)
 
 
-def build_new_account_plan(k=12, range_bits=11, range_chunks=11):
+def build_new_account_plan(k=12, range_bits=11, range_chunks=11, describe=False):
     """NewAccount-shaped stand-in on the same engine (same columns, gates and lookup as the withdraw plan):
       prenullifier  = H(id)                                              -> instance 1
       note          = H(id, nullifier, initial_deposit, token)           -> instance 0
@@ -101,10 +101,11 @@ def build_new_account_plan(k=12, range_bits=11, range_chunks=11):
     ElGamal (instances 7..10 are the two ciphertext points); that gadget lives in the un-vendored zkOS-circuits crate.
     Here the four coordinates are Poseidon2 placeholders, c1 = (H(salt, ar_x), H(salt, ar_y)), c2 = (H(id, c1x),
     H(id, c1y)): the argument vector, the 13 public inputs and their order are the reference's, the relation is not."""
-    return build_withdraw_plan(k, 0, range_bits, range_chunks, kind="new_account")
+    return build_withdraw_plan(k, 0, range_bits, range_chunks, kind="new_account", describe=describe)
 
 
-def build_withdraw_plan(k=13, height=13, range_bits=12, range_chunks=10, kind="withdraw"):
+def build_withdraw_plan(k=13, height=13, range_bits=12, range_chunks=10, kind="withdraw", describe=False):
+    """-> (circuit plan, layout); describe=True: (circuit description for shp_plan_compile, layout) instead"""
     b = PlanBuilder(k)
     lay = NewAccountLayout() if kind == "new_account" else WithdrawLayout(height, kind)
     b.n_winputs = lay.n_inputs
@@ -250,7 +251,7 @@ def build_withdraw_plan(k=13, height=13, range_bits=12, range_chunks=10, kind="w
     def finish():
         usable = b.n - (b.blinding_factors() + 1)
         assert state["row"] <= usable and (1 << range_bits) <= usable, "circuit does not fit 2^k rows"
-        return b.build(), lay
+        return (b.build_description() if describe else b.build()), lay
 
     if kind == "new_account":
         pre, r_pre = poseidon([("in", lay.ID)])
