@@ -1,0 +1,91 @@
+// CPU check of the 29-bit-limb Fq and its mixed addition against the 8 x 32-bit arithmetic (both compile for the host).
+// Exit code 0 and a line "ok ..." when every comparison holds; the first mismatch is printed and the exit code is 1.
+#include <stdio.h>
+#include <stdlib.h>
+#include "../../zkos-monorepo_amd/csrc/field29.cuh"
+
+using namespace shp;
+
+static uint64_t rng_state = 0x9e3779b97f4a7c15ull;
+static uint64_t rnd() {
+    rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+    return rng_state;
+}
+static Fq rnd_fq() {
+    Fq lo, hi;
+    for (int i = 0; i < 8; i++) { lo.l[i] = (uint32_t)rnd(); hi.l[i] = (uint32_t)rnd(); }
+    return Fq::from_u512(lo, hi);
+}
+static bool same_point(const G1X& a, const G1X& b) {
+    if (a.is_inf() || b.is_inf()) return a.is_inf() && b.is_inf();
+    const G1Affine x = g1_to_affine(a), y = g1_to_affine(b);
+    return x.x == y.x && x.y == y.y;
+}
+// v (Montgomery-2^261, lazy) as a canonical Montgomery-2^256 value
+static Fq canon(const Fq29& v) { return to_fq(v); }
+
+int main(int argc, char** argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 2000;
+    // 1. products and squares, operands pushed to the top of their allowed ranges by adding multiples of p
+    for (int it = 0; it < rounds; it++) {
+        const Fq a = rnd_fq(), b = rnd_fq();
+        Fq29 a29 = split29_dev<5>(a), b29 = from_fq_reduced(b);     // a29 < 32 p
+        const int extra = (int)(rnd() % 6);                         // b29 + extra * p < 7.1 p: 32 * 7.1 < 254
+        for (int e = 0; e < extra; e++) {
+            for (int i = 0; i < 9; i++) b29.l[i] += f29::P29.l[i];
+            normalise29(b29);
+        }
+        const Fq want = a * b;
+        if (canon(mul29(a29, b29)) != want) { printf("mul29 mismatch at %d\n", it); return 1; }
+        Fq29 s = from_fq_reduced(a);
+        const int extra2 = (int)(rnd() % 13);                       // up to 13.1 p: 13.1^2 < 254
+        for (int e = 0; e < extra2; e++) {
+            for (int i = 0; i < 9; i++) s.l[i] += f29::P29.l[i];
+            normalise29(s);
+        }
+        if (canon(sqr29(s)) != a * a) { printf("sqr29 mismatch at %d\n", it); return 1; }
+        if (canon(mul29(s, s)) != a * a) { printf("mul29(s, s) mismatch at %d\n", it); return 1; }
+        // a - b + K p
+        Fq29 ra = from_fq_reduced(a), rb = from_fq_reduced(b);
+        if (canon(sub29(ra, rb, f29::KP3)) != a - b) { printf("sub29 mismatch at %d\n", it); return 1; }
+    }
+    // 2. chains of mixed additions, with the exceptional cases spliced in
+    Fq gx = Fq::one(), gy = Fq::one() + Fq::one();                  // the generator (1, 2)
+    const int n_pts = 64;
+    G1Affine pts[n_pts];
+    G1X run = G1X::inf();
+    for (int i = 0; i < n_pts; i++) {
+        const int reps = 1 + (int)(rnd() % 5);
+        for (int r = 0; r < reps; r++) run = g1_madd(run, gx, gy);
+        if (i % 7 == 3) run = g1_dbl(run);
+        pts[i] = g1_to_affine(run);
+    }
+    long adds = 0;
+    for (int it = 0; it < rounds / 10 + 1; it++) {
+        G1X ref = G1X::inf();
+        G1X29 acc;
+        acc.inf = true;
+        G1Affine last = pts[0];
+        const int len = 1 + (int)(rnd() % 40);
+        for (int s = 0; s < len; s++) {
+            G1Affine q = pts[rnd() % n_pts];
+            const uint64_t kind = rnd() % 16;
+            if (kind == 0 && s > 0) q = last;                        // often a doubling (when the accumulator equals q)
+            if (kind == 1 && s > 0) {                                // accumulator == q exactly: force it
+                if (!ref.is_inf()) q = g1_to_affine(ref);
+            }
+            if (kind == 2 && s > 0 && !ref.is_inf()) {               // accumulator == -q: the sum is the identity
+                q = g1_to_affine(ref);
+                q.y = Fq::neg(q.y);
+            }
+            if (kind == 3) q.y = Fq::neg(q.y);
+            ref = g1_madd(ref, q.x, q.y);
+            g1_madd29(acc, q.x, q.y);
+            adds++;
+            last = q;
+            if (!same_point(to_g1x(acc), ref)) { printf("madd29 mismatch: chain %d step %d kind %d\n", it, s, (int)kind); return 1; }
+        }
+    }
+    printf("ok %d products, %ld additions\n", rounds, adds);
+    return 0;
+}

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "engine.hpp"
+#include "field29.cuh"
 
 namespace shp {
 
@@ -216,24 +217,26 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const G1Aff
     }
     uint32_t cur = lo;
     uint32_t boundary = s[cur + 1];
-    G1X acc = G1X::inf();
+    // the running sum lives in the 29-bit-limb form (field29.cuh); it is converted when a run ends
+    G1X29 acc;
+    acc.inf = true;
     bool first_run = true;
     pl->bucket = BUCKET_NONE;
     for (uint32_t pos = begin; pos < end; pos++) {
         if (pos >= boundary) {
-            if (first_run) { pf->sum = acc; pf->bucket = cur; first_run = false; }
-            else bk[cur] = acc;
-            acc = G1X::inf();
+            if (first_run) { pf->sum = to_g1x(acc); pf->bucket = cur; first_run = false; }
+            else bk[cur] = to_g1x(acc);
+            acc.inf = true;
             do { cur++; boundary = s[cur + 1]; } while (pos >= boundary);
         }
         uint32_t e = ent[pos];
         G1Affine p = table[e & 0x7fffffffu];
         if (p.is_inf()) continue;
         Fq y = (e >> 31) ? Fq::neg(p.y) : p.y;
-        acc = g1_madd(acc, p.x, y);
+        g1_madd29(acc, p.x, y);
     }
-    if (first_run) { pf->sum = acc; pf->bucket = cur; }
-    else { pl->sum = acc; pl->bucket = cur; }
+    if (first_run) { pf->sum = to_g1x(acc); pf->bucket = cur; }
+    else { pl->sum = to_g1x(acc); pl->bucket = cur; }
 }
 
 __device__ __forceinline__ G1X shfl_xor_point(const G1X& p, int mask) {
@@ -642,6 +645,7 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
 
 // lane <-> scalar i, blockIdx.y <-> group of T windows, blockIdx.x <-> (segment, MSM of its batch, 256-row block):
 // only row blocks a segment visits are launched (an empty workgroup still costs ~0.1 us of dispatch)
+template <bool LAZY29>
 __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a) {
     __shared__ uint32_t sh[COOP_LDS_WORDS];
     uint32_t lo = 0, hi = a.n_segs;                            // last segment with wg_base <= blockIdx.x
@@ -660,6 +664,8 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
     const uint32_t w0 = blockIdx.y * a.T;
     const uint32_t w1 = w0 + a.T < a.W ? w0 + a.T : a.W;
     G1X acc = G1X::inf();
+    G1X29 acc29;
+    acc29.inf = true;
     if (lane < visited) {
         Fr raw = load_fr(sg.scalars + (size_t)m * sg.stride + i).to_raw();
         if (!raw.is_zero()) {
@@ -699,10 +705,12 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
                 if (slot != (size_t)-1) p = load_affine(mult + slot);
                 if (cur.is_inf()) continue;
                 const Fq y = cur_neg ? Fq::neg(cur.y) : cur.y;
-                acc = g1_madd(acc, cur.x, y);
+                if constexpr (LAZY29) g1_madd29(acc29, cur.x, y);
+                else acc = g1_madd(acc, cur.x, y);
             }
         }
     }
+    if constexpr (LAZY29) acc = to_g1x(acc29);
     acc = block_sum_256(acc, sh);
     if (threadIdx.x == 0) a.partials[part] = acc;
 }
@@ -922,7 +930,9 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
     a.c = m0->c; a.W = W; a.NB = m0->NB; a.T = T; a.bias = m0->bias; a.partials = ws.pf.as<G1X>();
     KernelTimers none, *tm = ws.timers ? ws.timers : &none;
     tm->begin(KID_MSM_DIRECT, st);
-    hipLaunchKernelGGL(msm_direct_kernel, dim3((uint32_t)busy_wgs, gy), dim3(MSM_THREADS), 0, st, a);
+    static const bool lazy29 = !(getenv("SHP_MSM_LAZY29") && atoi(getenv("SHP_MSM_LAZY29")) == 0);
+    if (lazy29) hipLaunchKernelGGL(msm_direct_kernel<true>, dim3((uint32_t)busy_wgs, gy), dim3(MSM_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(msm_direct_kernel<false>, dim3((uint32_t)busy_wgs, gy), dim3(MSM_THREADS), 0, st, a);
     tm->end(st);
     tm->begin(KID_MSM_DIRECT_FINAL, st);
     hipLaunchKernelGGL(msm_direct_final_kernel, dim3((uint32_t)total), dim3(MSM_THREADS), 0, st, a.segs, n_jobs, gy,
