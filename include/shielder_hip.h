@@ -64,6 +64,13 @@ int32_t shp_device_count(int32_t* out);
 int32_t shp_ctx_create(int32_t device, shp_ctx** out);
 int32_t shp_ctx_destroy(shp_ctx* ctx);
 int32_t shp_ctx_sync(shp_ctx* ctx);                       /* wait for the context's stream */
+/* Caps the device memory the whole process may hold while this context sizes its MSM tables (0 = no cap, the default).
+ * Every multiples table is sized against what hipMemGetInfo reports free (and this cap): a table takes at most half of
+ * the free memory beyond 6 GiB of headroom, stepping its window down (each step halves the table) and, below 2^8-entry
+ * windows, falling back to the bucket method -- an SRS never fails to load for want of table space.  Stands where the
+ * reference's Params::read keeps only the 2^k points themselves (crates/powers-of-tau/lib.rs:206-227): the tables are this
+ * library's own precomputation. */
+int32_t shp_ctx_set_hbm_limit(shp_ctx* ctx, uint64_t bytes);
 /* the context's hipStream_t (so that a caller can order its own copies/kernels on it) */
 int32_t shp_ctx_stream(shp_ctx* ctx, void** stream_out);
 
@@ -126,6 +133,9 @@ int32_t shp_msm_destroy(shp_msm* m);
  * `stride_elems` elements) against the same bases -> `batch` affine points (host, 64 B each). */
 int32_t shp_msm_g1(shp_msm* m, const void* d_scalars, size_t n_scalars, size_t stride_elems, uint32_t batch,
                    void* h_out_affine, void* stream);
+/* how the plan evaluates: direct != 0 for a full multiples table (one gather and one addition per non-zero digit),
+ * 0 for the bucket method; the window width; device bytes held by its tables */
+int32_t shp_msm_info(const shp_msm* m, int32_t* direct, uint32_t* window_bits, uint64_t* table_bytes);
 /* bytes of algorithmic HBM traffic and group operations of the last shp_msm_g1 call */
 int32_t shp_msm_last_stats(shp_msm* m, uint64_t* point_adds, uint64_t* bytes);
 
@@ -169,6 +179,8 @@ int32_t shp_srs_downsize(const shp_srs* srs, uint32_t k, shp_srs** out);
  * (k | g | g_lagrange | g2 | s_g2, little-endian Montgomery coordinates) -- byte for byte the layout of the
  * reference's resources/ppot_0080_11_raw; shp_srs_from_halo2_raw reads it back.  out == NULL only reports the length. */
 int32_t shp_srs_save(const shp_srs* srs, uint8_t* out, size_t out_cap, size_t* out_len);
+/* shp_msm_info of the SRS's own plan for one basis (SHP_BASIS_MONOMIAL / SHP_BASIS_LAGRANGE) */
+int32_t shp_srs_msm_info(const shp_srs* srs, int32_t basis, int32_t* direct, uint32_t* window_bits, uint64_t* table_bytes);
 int32_t shp_srs_destroy(shp_srs* srs);
 int32_t shp_srs_k(const shp_srs* srs, uint32_t* k);
 /* copies of the tables / G2 elements back to the host (Params::get_g, g2, s_g2) */

@@ -6,7 +6,6 @@ Server and clients share one process (asyncio); the clients verify nothing, they
 import argparse, asyncio, importlib, json, os, random, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 shp = importlib.import_module("zkos-monorepo_amd")
 circuits = importlib.import_module("zkos-monorepo_amd.circuits")
 S = importlib.import_module("zkos-monorepo_amd.serve")

@@ -5,7 +5,6 @@ import argparse, importlib, os, random, sys, time
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 shp = importlib.import_module("zkos-monorepo_amd")
 circuits = importlib.import_module("zkos-monorepo_amd.circuits")
 

@@ -77,6 +77,29 @@ __device__ __forceinline__ void mul29(const uint32_t a[9], const uint32_t b[9], 
     r[8] = (uint32_t)acc;
 }
 
+// D: the same product by ROWS: 18 independent 64-bit column accumulators, so consecutive v_mad_u64_u32 never depend on
+// each other (in B a column is one chain of up to 18 dependent instructions); costs a 64-bit carry addition per column
+__device__ __forceinline__ void mul29_rows(const uint32_t a[9], const uint32_t b[9], uint32_t r[9], const P29& P) {
+    uint64_t t[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) t[i] = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[k + j] += (uint64_t)a[k] * b[j];
+        const uint32_t q = ((uint32_t)t[k] * P.pinv) & M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) t[k + j] += (uint64_t)q * P.p[j];
+        t[k + 1] += t[k] >> 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+        t[k + 1] += t[k] >> 29;
+        r[k - 9] = (uint32_t)t[k] & M29;
+    }
+    r[8] = (uint32_t)t[17];
+}
+
 // ------------------------------------------------------------------------------------------------ C: 5 x 52 bits in doubles
 struct P52 {
     double p[5];
@@ -154,6 +177,20 @@ __global__ __launch_bounds__(256) void chain_lazy29(const Fq* in, Fq* out, uint3
     to29(in[2 * t + 1].l, y);
     for (uint32_t i = 0; i < iters; i++) {
         mul29(x, y, r, P);
+#pragma unroll
+        for (int j = 0; j < 9; j++) x[j] = r[j];
+    }
+    Fq o;
+    from29(x, o.l);
+    out[t] = o;
+}
+__global__ __launch_bounds__(256) void chain_lazy29_rows(const Fq* in, Fq* out, uint32_t iters, P29 P) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x[9], y[9], r[9];
+    to29(in[2 * t].l, x);
+    to29(in[2 * t + 1].l, y);
+    for (uint32_t i = 0; i < iters; i++) {
+        mul29_rows(x, y, r, P);
 #pragma unroll
         for (int j = 0; j < 9; j++) x[j] = r[j];
     }
@@ -253,16 +290,17 @@ int main() {
     hipMalloc(&d_in, h_in.size() * sizeof(Fq));
     hipMalloc(&d_out, h_out.size() * sizeof(Fq));
     hipMemcpy(d_in, h_in.data(), h_in.size() * sizeof(Fq), hipMemcpyHostToDevice);
-    const dim3 grid(threads / 256), block(256);
+    dim3 grid(threads / 256), block(256);
     auto launch = [&](int which, uint32_t iters) {
         if (which == 0) hipLaunchKernelGGL(chain_fips32, grid, block, 0, 0, d_in, d_out, iters);
         else if (which == 1) hipLaunchKernelGGL(chain_lazy29, grid, block, 0, 0, d_in, d_out, iters, p29);
-        else hipLaunchKernelGGL(chain_fp64x52, grid, block, 0, 0, d_in, d_out, iters, p52);
+        else if (which == 2) hipLaunchKernelGGL(chain_fp64x52, grid, block, 0, 0, d_in, d_out, iters, p52);
+        else hipLaunchKernelGGL(chain_lazy29_rows, grid, block, 0, 0, d_in, d_out, iters, p29);
     };
     // ---- validation: `iters` dependent products x <- x y 2^-w against the library's Fq::mul on the host
-    const char* names[3] = {"A fips32 (shipped)", "B lazy29", "C fp64x52"};
-    const uint32_t rbits[3] = {256, 261, 260};
-    for (int which = 0; which < 3; which++) {
+    const char* names[4] = {"A fips32", "B lazy29 (columns)", "C fp64x52", "D lazy29 (rows)"};
+    const uint32_t rbits[4] = {256, 261, 260, 261};
+    for (int which = 0; which < 4; which++) {
         const uint32_t iters = 7;
         launch(which, iters);
         hipDeviceSynchronize();
@@ -281,7 +319,11 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int which = 0; which < 3; which++) {
+    // at 8 waves per SIMD and then at the occupancies the MSM kernels really run at (their 130-160 VGPRs allow 3)
+    for (int wps : {8, 4, 3, 2, 1})
+    for (int which = 0; which < 4; which++) {
+        grid = dim3((uint32_t)cus * wps);                                    // 4 waves a workgroup: wps waves per SIMD
+        const uint32_t threads_now = grid.x * 256;
         auto timed = [&](uint32_t iters) {
             hipEventRecord(e0, 0);
             launch(which, iters);
@@ -293,13 +335,13 @@ int main() {
         };
         const uint32_t n1 = 2000, n2 = 4000;
         double warm = 0;
-        while (warm < 50.0) warm += timed(n2);
+        while (warm < (wps == 8 && which == 0 ? 50.0 : 5.0)) warm += timed(n2);
         double t1 = 1e30, t2 = 1e30;
         for (int rep = 0; rep < 3; rep++) { t1 = std::min(t1, timed(n1)); t2 = std::min(t2, timed(n2)); }
-        const double per_s = (double)threads * (n2 - n1) / ((t2 - t1) * 1e-3);
+        const double per_s = (double)threads_now * (n2 - n1) / ((t2 - t1) * 1e-3);
         const double cyc = clk * 1e9 / (per_s / 64.0 / (cus * 4.0));          // cycles one SIMD spends per wave-product
-        printf("%-20s %.3f ms @%u  %.3f ms @%u  -> %.1f G products/s, %.0f SIMD cycles per wave-product (= instructions at 4 cycles: %.0f)\n",
-               names[which], t1, n1, t2, n2, per_s * 1e-9, cyc, cyc / 4.0);
+        printf("%d waves/SIMD  %-20s %.3f ms @%u  %.3f ms @%u  -> %.1f G products/s, %.0f SIMD cycles per wave-product (= instructions at 4 cycles: %.0f)\n",
+               wps, names[which], t1, n1, t2, n2, per_s * 1e-9, cyc, cyc / 4.0);
     }
     return 0;
 }

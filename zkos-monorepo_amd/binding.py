@@ -52,10 +52,17 @@ def lib():
         # torch (plumbing: device memory, streams) bundles its own HIP runtime and loads it RTLD_GLOBAL;
         # importing it FIRST makes libshielder_hip resolve its hip* symbols to that same runtime
         # instance, so stream handles and device pointers are interchangeable between the two.
-        # Proving lanes are HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
-        # (default 4), and streams that share a queue serialise.  Must be set before the HIP runtime
-        # initialises (measured, 16 lanes: 614 -> 789 proofs/s).
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        # Proving lanes are HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (HIP's default
+        # is 4, and hosts export it), and kernels of streams that share a queue run one after the other (measured,
+        # 16 lanes: 1149 proofs/s on 4 queues, 1400 on 16).  Must be in the environment before the HIP runtime
+        # initialises, which torch's import below may do; SHP_KEEP_HW_QUEUES=1 leaves the environment alone.
+        if os.environ.get("SHP_KEEP_HW_QUEUES") != "1":
+            try:
+                cur = int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
+            except ValueError:
+                cur = 0
+            if cur < 16:
+                os.environ["GPU_MAX_HW_QUEUES"] = "16"
         import torch  # noqa: F401
         _lib = C.CDLL(_SO)
         _lib.shp_last_error.restype = C.c_char_p
@@ -128,6 +135,10 @@ class Context:
 
     def sync(self):
         _check(lib().shp_ctx_sync(self.h))
+
+    def set_hbm_limit(self, nbytes: int):
+        """cap on the device memory the process may hold while MSM tables are sized (0: none)"""
+        _check(lib().shp_ctx_set_hbm_limit(self.h, C.c_uint64(int(nbytes))))
 
     def fr_mul_rate(self, iters=4096):
         out = C.c_double()
@@ -223,6 +234,12 @@ class Params:
         h = C.c_void_p()
         _check(lib().shp_srs_from_ptau(ctx.h, C.c_char_p(data), C.c_size_t(len(data)), C.byref(h)))
         return cls(ctx, h)
+
+    def msm_info(self, basis=1):
+        """(direct, window_bits, table_bytes) of the SRS's MSM plan for one basis"""
+        d, c, b = C.c_int32(), C.c_uint32(), C.c_uint64()
+        _check(lib().shp_srs_msm_info(self.h, C.c_int32(basis), C.byref(d), C.byref(c), C.byref(b)))
+        return bool(d.value), c.value, b.value
 
     def downsize(self, k: int):
         """Params::downsize: a new Params over the first 2^k powers (reference shielder-cli pk.rs:110)"""

@@ -163,12 +163,19 @@ static void read_points(const uint8_t* p, size_t n, std::vector<G1Affine>& out) 
     }
 }
 
-// Proving lanes are HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default
-// 4) and streams sharing a queue serialise.  Runs at load time, i.e. before this library's first HIP
-// call; it has no effect if the host process initialised HIP earlier with another value.
+// Proving lanes are HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (HIP's default is 4, and
+// hosts export that value explicitly) and the kernels of streams that share a queue run one after the other: 16 lanes
+// on 4 queues prove 1149 proofs/s, on 16 queues 1400.  A missing or smaller value is raised to 16 at load time, i.e.
+// before this library's first HIP call (SHP_KEEP_HW_QUEUES=1 leaves the environment alone); it has no effect if the
+// host process initialised HIP earlier.
 namespace {
 struct HwQueueDefault {
-    HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+    HwQueueDefault() {
+        const char* keep = getenv("SHP_KEEP_HW_QUEUES");
+        if (keep && atoi(keep) == 1) return;
+        const char* cur = getenv("GPU_MAX_HW_QUEUES");
+        if (!cur || atoi(cur) < 16) setenv("GPU_MAX_HW_QUEUES", "16", 1);
+    }
 } g_hw_queue_default;
 }  // namespace
 
@@ -233,6 +240,24 @@ int32_t shp_ctx_destroy(shp_ctx* ctx) {
         ntt_static_teardown(ctx);
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
+    });
+}
+
+int32_t shp_ctx_set_hbm_limit(shp_ctx* ctx, uint64_t bytes) {
+    return guarded([&] {
+        SHP_REQUIRE(ctx, SHP_ERR_INVALID_ARG, "ctx_set_hbm_limit: null context");
+        ctx->hbm_limit.store(bytes);
+    });
+}
+
+int32_t shp_srs_msm_info(const shp_srs* srs, int32_t basis, int32_t* direct, uint32_t* window_bits, uint64_t* table_bytes) {
+    return guarded([&] {
+        SHP_REQUIRE(srs && (basis == SHP_BASIS_MONOMIAL || basis == SHP_BASIS_LAGRANGE), SHP_ERR_INVALID_ARG,
+                    "srs_msm_info: null SRS or unknown basis");
+        const shp_msm* m = basis == SHP_BASIS_LAGRANGE ? srs->msm_gl : srs->msm_g;
+        SHP_REQUIRE(m, SHP_ERR_INVALID_ARG, "srs_msm_info: the SRS has no tables for this basis");
+        int32_t rc = shp_msm_info(m, direct, window_bits, table_bytes);
+        SHP_REQUIRE(rc == SHP_OK, rc, shp_last_error());
     });
 }
 

@@ -18,14 +18,15 @@ void set_last_error(const std::string& msg);
 
 struct Error : std::runtime_error {
     int32_t code;
-    Error(int32_t c, const std::string& m) : std::runtime_error(m), code(c) {}
+    int hip_code;       // the hipError_t behind an SHP_ERR_HIP (0 otherwise)
+    Error(int32_t c, const std::string& m, int hip = 0) : std::runtime_error(m), code(c), hip_code(hip) {}
 };
 
 #define SHP_HIP(expr)                                                                         \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \
         if (_e != hipSuccess)                                                                 \
-            throw ::shp::Error(SHP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+            throw ::shp::Error(SHP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e), (int)_e); \
     } while (0)
 
 #define SHP_REQUIRE(cond, code, msg)                          \

@@ -1,5 +1,6 @@
 // The per-(process, GPU) context behind shp_ctx.
 #pragma once
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -37,6 +38,7 @@ struct shp_ctx {
     shp::Fr* ntt_master_hi[2] = {nullptr, nullptr};
     shp::Fr* ntt_static_tmp = nullptr;
     shp::Fr zeta, zeta2;                                  // coset generator of the extended domain
+    std::atomic<uint64_t> hbm_limit{0};                   // bytes the process may hold on the device (0: no cap)
 
     hipStream_t pick(void* s) const { return s ? reinterpret_cast<hipStream_t>(s) : stream; }
 };

@@ -188,6 +188,17 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_scan_kernel(const uint32_t* c
     if (t == 0) s[0] = 0;
 }
 
+__device__ __forceinline__ G1Affine load_affine(const G1Affine* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    G1Affine r;
+    r.x.l[0] = a.x; r.x.l[1] = a.y; r.x.l[2] = a.z; r.x.l[3] = a.w;
+    r.x.l[4] = b.x; r.x.l[5] = b.y; r.x.l[6] = b.z; r.x.l[7] = b.w;
+    r.y.l[0] = c.x; r.y.l[1] = c.y; r.y.l[2] = c.z; r.y.l[3] = c.w;
+    r.y.l[4] = d.x; r.y.l[5] = d.y; r.y.l[6] = d.z; r.y.l[7] = d.w;
+    return r;
+}
+
 // ---------------------------------------------------------------- chunked bucket accumulation
 __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const G1Affine* __restrict__ table,
                                                                      const uint32_t* __restrict__ entries,
@@ -482,17 +493,6 @@ struct DirectArgs {
     G1X* partials;
 };
 
-__device__ __forceinline__ G1Affine load_affine(const G1Affine* p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    uint4 a = q[0], b = q[1], c = q[2], d = q[3];
-    G1Affine r;
-    r.x.l[0] = a.x; r.x.l[1] = a.y; r.x.l[2] = a.z; r.x.l[3] = a.w;
-    r.x.l[4] = b.x; r.x.l[5] = b.y; r.x.l[6] = b.z; r.x.l[7] = b.w;
-    r.y.l[0] = c.x; r.y.l[1] = c.y; r.y.l[2] = c.z; r.y.l[3] = c.w;
-    r.y.l[4] = d.x; r.y.l[5] = d.y; r.y.l[6] = d.z; r.y.l[7] = d.w;
-    return r;
-}
-
 // Sum of one XYZZ point per thread over a 256-thread workgroup; the result is valid in thread 0.
 //
 // The points live in LDS in [coordinate][limb][slot] order (conflict free).  Level 256 -> 128 is one
@@ -760,13 +760,32 @@ static uint32_t direct_windows(uint32_t c) {
     return W;
 }
 
-// largest c in [8, 14] whose full multiples table fits the budget (0 = none: use buckets)
-static uint32_t pick_direct_window(size_t n) {
-    const double budget = direct_budget_gib() * 1073741824.0;
-    for (uint32_t c = 14; c >= 8; c--) {
-        double bytes = (double)n * direct_windows(c) * (double)(1u << (c - 1)) * sizeof(G1Affine);
-        if (bytes <= budget) return c;
+static double direct_table_bytes(size_t n, uint32_t c) {
+    return (double)n * direct_windows(c) * (double)(1u << (c - 1)) * sizeof(G1Affine);
+}
+
+// HBM the library may still take on the current device: what hipMemGetInfo reports free, capped by the context's limit
+// (shp_ctx_set_hbm_limit: bytes the whole process may hold on the device, 0 = no cap)
+static double hbm_available(shp_ctx* ctx) {
+    size_t free_b = 0, total_b = 0;
+    SHP_HIP(hipMemGetInfo(&free_b, &total_b));
+    double avail = (double)free_b;
+    const uint64_t limit = ctx->hbm_limit.load();
+    if (limit) {
+        const double used = (double)total_b - (double)free_b;
+        avail = std::min(avail, std::max(0.0, (double)limit - used));
     }
+    return avail;
+}
+
+// largest c in [8, below] whose full multiples table fits both the per-table budget and the device: a table may take half
+// of what is free after 6 GiB of headroom (build scratch, proving workspaces), the other half being left for the sibling
+// basis that every SRS builds next.  0 = none fits: use buckets.
+static uint32_t pick_direct_window(shp_ctx* ctx, size_t n, uint32_t below = 15) {
+    const double gib = 1073741824.0;
+    const double budget = std::min(direct_budget_gib() * gib, (hbm_available(ctx) - 6.0 * gib) / 2.0);
+    for (uint32_t c = std::min<uint32_t>(14, below - 1); c >= 8; c--)
+        if (direct_table_bytes(n, c) <= budget) return c;
     return 0;
 }
 
@@ -809,15 +828,26 @@ static void msm_build(shp_ctx* ctx, const G1Affine* d_bases, size_t n, uint32_t 
     m->n = n;
     // window_bits == 0: direct multiples table when it fits the HBM budget, buckets otherwise;
     // an explicit window_bits always selects the bucket method with that window
-    uint32_t cd = window_bits ? 0 : pick_direct_window(n);
-    if (cd) {
+    uint32_t cd = window_bits ? 0 : pick_direct_window(ctx, n);
+    while (cd) {
         m->direct = true;
         m->c = cd;
         m->W = direct_windows(cd);
         m->NB = 1u << (cd - 1);
-        msm_build_direct(ctx, m.get(), d_bases);
-        *out = m.release();
-        return;
+        try {
+            msm_build_direct(ctx, m.get(), d_bases);
+            *out = m.release();
+            return;
+        } catch (const Error& e) {
+            // another allocator got there first: give the partial tables back, step the window down (each step halves
+            // the table; c = 12 costs 3.5 % of proving throughput) and, below c = 8, fall through to the bucket method
+            if (e.hip_code != (int)hipErrorOutOfMemory) throw;
+            (void)hipGetLastError();
+            if (m->d_table) { (void)hipFree(m->d_table); m->d_table = nullptr; }
+            if (m->d_mult) { (void)hipFree(m->d_mult); m->d_mult = nullptr; }
+            m->direct = false;
+            cd = pick_direct_window(ctx, n, cd);
+        }
     }
     uint32_t c = window_bits ? window_bits : pick_window(n);
     SHP_REQUIRE(c >= 2 && c <= 20, SHP_ERR_INVALID_ARG, "msm_create: window_bits must be in [2,20]");
@@ -1194,6 +1224,16 @@ int32_t shp_msm_last_stats(shp_msm* m, uint64_t* point_adds, uint64_t* bytes) {
         SHP_REQUIRE(m, SHP_ERR_INVALID_ARG, "msm: null plan");
         if (point_adds) *point_adds = m->ws.last_adds;
         if (bytes) *bytes = m->ws.last_bytes;
+    });
+}
+
+int32_t shp_msm_info(const shp_msm* m, int32_t* direct, uint32_t* window_bits, uint64_t* table_bytes) {
+    return guarded([&] {
+        SHP_REQUIRE(m, SHP_ERR_INVALID_ARG, "msm: null plan");
+        if (direct) *direct = m->direct ? 1 : 0;
+        if (window_bits) *window_bits = m->c;
+        if (table_bytes)
+            *table_bytes = (uint64_t)m->W * m->n * sizeof(G1Affine) * (m->direct ? (uint64_t)m->NB + 1 : 1);
     });
 }
 
