@@ -14,11 +14,10 @@ namespace shp {
 // `roofline` object needs the dominant kernel's average launch duration measured live).
 enum KernelId {
     KID_MSM_DIGITS = 0, KID_MSM_ACCUMULATE, KID_MSM_FIXUP, KID_MSM_REDUCE, KID_NTT, KID_PROG, KID_GRAND_PRODUCT,
-    KID_RANK_SORT, KID_BATCH_INVERT, KID_MSM_DIRECT, KID_MSM_DIRECT_FINAL, KID_COUNT
+    KID_RANK_SORT, KID_BATCH_INVERT, KID_MSM_DIRECT, KID_COUNT
 };
 static const char* const KERNEL_NAMES[KID_COUNT] = {"msm_digits", "msm_accumulate", "msm_fixup", "msm_reduce", "ntt_pass",
-                                                    "prog_fold", "grand_product", "rank_sort", "batch_invert", "msm_direct",
-                                                    "msm_direct_final"};
+                                                    "prog_fold", "grand_product", "rank_sort", "batch_invert", "msm_direct"};
 struct KernelTimers {
     bool enabled = false;
     struct Rec { int id; hipEvent_t a, b; };
@@ -69,6 +68,8 @@ struct MsmWorkspace {
     KernelTimers* timers = nullptr;
     DevBuf cnt, start, entries, pf, pl, buckets, out, wg_hist;
     PinnedBuf h_out, h_totals;             // G1X sums / per-MSM entry counts, read back after each run
+    DevBuf done;                           // direct mode: per-MSM count of finished workgroups (zero between launches)
+    size_t done_zeroed = 0;                // bytes of `done` known to be zero
     DevBuf segs;                           // direct mode: segment tables (16 cached slots of 4 + scratch)
     PinnedBuf h_segs;
     uint32_t seg_cached = 0, seg_cache_n[16] = {0};
@@ -78,6 +79,7 @@ struct MsmWorkspace {
     void release() {
         cnt.release(); start.release(); entries.release(); pf.release(); pl.release(); buckets.release(); out.release();
         wg_hist.release(); h_out.release(); h_totals.release(); segs.release(); h_segs.release(); seg_cached = 0;
+        done.release(); done_zeroed = 0;
     }
 };
 

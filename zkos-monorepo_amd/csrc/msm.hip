@@ -491,6 +491,8 @@ struct DirectArgs {
     uint32_t c, W, NB, T;
     Fr bias;
     G1X* partials;
+    uint32_t* done;       // per MSM of the launch: workgroups that have stored their partial sum
+    G1X* out;             // per MSM: the sum (may be pinned host memory)
 };
 
 // Sum of one XYZZ point per thread over a 256-thread workgroup; the result is valid in thread 0.
@@ -712,26 +714,28 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
     }
     if constexpr (LAZY29) acc = to_g1x(acc29);
     acc = block_sum_256(acc, sh);
-    if (threadIdx.x == 0) a.partials[part] = acc;
-}
-
-// one workgroup per MSM of the launch: sum of its gx * gy partials
-__global__ __launch_bounds__(MSM_THREADS) void msm_direct_final_kernel(const DirectSeg* segs, uint32_t n_segs, uint32_t gy,
-                                                                       const G1X* partials, G1X* out) {
-    __shared__ uint32_t sh[COOP_LDS_WORDS];
-    const uint32_t g = blockIdx.x;
-    uint32_t lo = 0, hi = n_segs;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (segs[mid].msm_base <= g) lo = mid; else hi = mid;
+    // The workgroup that stores the last partial sum of an MSM adds them all up: no second dispatch (on a busy chip a
+    // dispatch costs its stream tens of microseconds whatever its size).  Device-scope fences on both sides of the
+    // count make the partials of workgroups on other XCDs (other L2s) visible to the one that reads them.
+    __shared__ uint32_t is_last;
+    const uint32_t P = sg.gx * gridDim.y;
+    uint32_t* const done = a.done + sg.msm_base + m;
+    if (threadIdx.x == 0) {
+        a.partials[part] = acc;
+        __threadfence();
+        is_last = atomicAdd(done, 1u) + 1 == P;
     }
-    const DirectSeg sg = segs[lo];
-    const uint32_t P = sg.gx * gy;
-    const G1X* p = partials + sg.part_base + (size_t)(g - sg.msm_base) * P;
-    G1X acc = G1X::inf();
-    for (uint32_t j = threadIdx.x; j < P; j += MSM_THREADS) acc = g1_add(acc, p[j]);
-    acc = block_sum_256(acc, sh, P < MSM_THREADS ? P : MSM_THREADS);
-    if (threadIdx.x == 0) out[g] = acc;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const G1X* p = a.partials + sg.part_base + (size_t)m * P;
+    G1X sum = G1X::inf();
+    for (uint32_t j = threadIdx.x; j < P; j += MSM_THREADS) sum = g1_add(sum, p[j]);
+    sum = block_sum_256(sum, sh, P < MSM_THREADS ? P : MSM_THREADS);
+    if (threadIdx.x == 0) {
+        a.out[sg.msm_base + m] = sum;
+        *done = 0;                                             // ready for the next launch
+    }
 }
 
 }  // namespace shp
@@ -929,6 +933,11 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
     }
     ws.pf.reserve(parts * sizeof(G1X));
     ws.h_out.reserve(total * sizeof(G1X));                     // before the launch: the final sums are written
+    ws.done.reserve(std::max<size_t>(total, 256) * sizeof(uint32_t));
+    if (ws.done_zeroed != ws.done.cap) {                       // grown (or new): the counters start at zero, and every
+        SHP_HIP(hipMemsetAsync(ws.done.p, 0, ws.done.cap, st));   // launch leaves them at zero again
+        ws.done_zeroed = ws.done.cap;
+    }
     // segment tables live in a small device arena: a prover's six commitment phases present the same tables
     // proof after proof (same buffers, same shapes), so short tables are uploaded once and found again by
     // content; longer or novel ones (a combiner's mixes) go through the scratch region behind the cache slots
@@ -958,15 +967,13 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
     a.segs = ws.segs.as<DirectSeg>() + seg_at; a.n_segs = n_jobs;
     a.n_table = m0->n;
     a.c = m0->c; a.W = W; a.NB = m0->NB; a.T = T; a.bias = m0->bias; a.partials = ws.pf.as<G1X>();
+    a.done = ws.done.as<uint32_t>();
+    a.out = ws.h_out.as<G1X>();                                // straight into pinned host memory: no copy dispatch
     KernelTimers none, *tm = ws.timers ? ws.timers : &none;
     tm->begin(KID_MSM_DIRECT, st);
     static const bool lazy29 = !(getenv("SHP_MSM_LAZY29") && atoi(getenv("SHP_MSM_LAZY29")) == 0);
     if (lazy29) hipLaunchKernelGGL(msm_direct_kernel<true>, dim3((uint32_t)busy_wgs, gy), dim3(MSM_THREADS), 0, st, a);
     else hipLaunchKernelGGL(msm_direct_kernel<false>, dim3((uint32_t)busy_wgs, gy), dim3(MSM_THREADS), 0, st, a);
-    tm->end(st);
-    tm->begin(KID_MSM_DIRECT_FINAL, st);
-    hipLaunchKernelGGL(msm_direct_final_kernel, dim3((uint32_t)total), dim3(MSM_THREADS), 0, st, a.segs, n_jobs, gy,
-                       ws.pf.as<G1X>(), ws.h_out.as<G1X>());   // straight into pinned host memory: no copy dispatch
     tm->end(st);
     SHP_HIP(hipGetLastError());
     shp::sync_stream(st);

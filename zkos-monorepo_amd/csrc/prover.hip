@@ -589,16 +589,16 @@ struct shp_prover {
     Fr *cin = nullptr, *ctab = nullptr;                        // [L][n] compressed lookup input / table
     Fr *num = nullptr, *den = nullptr;                         // [S + L][n]
     Fr *sort_raw = nullptr, *sort_out = nullptr;               // [2L][n]
-    uint32_t *rep_scratch = nullptr, *err = nullptr;
+    uint32_t* rep_scratch = nullptr;
     Fr *rand_poly = nullptr, *h = nullptr, *aux_ext = nullptr; // h [ne], aux_ext [2][ne]
     Fr *hx = nullptr, *lag2 = nullptr;                         // hx coeffs; [2][n] Lagrange values of hx, rand
-    Fr *pw = nullptr, *points = nullptr;
-    EvalJob* jobs = nullptr;
+    Fr* pw = nullptr;
+    EvalJob* jobs = nullptr;                                   // fixed per prover (buffer addresses, point indices): uploaded once
+    bool jobs_uploaded = false;
     Fr *fsets = nullptr, *pdiff = nullptr, *dinv = nullptr, *wvals = nullptr, *mdiff = nullptr;
-    LincombArgs* lin = nullptr;
-    ShplonkArgs* shp_args = nullptr;
-    Fr *blinds = nullptr, *ntt_tmp = nullptr;
-    uint32_t* key = nullptr;
+    ShplonkArgs* shp_args = nullptr;                           // one arena: the SHPLONK arguments, then the rotation
+    LincombArgs* lin = nullptr;                                // sets' combinations right behind them (one upload)
+    Fr* ntt_tmp = nullptr;
     Fr* h_grid = nullptr;                                      // pinned host staging of the witness grid
     // The grid and the device columns are cleared once; the witness program rewrites the same cells every proof.  A proof
     // from caller-assigned columns (shp_prove_assigned) writes other cells: grid_foreign makes the next witness-program
@@ -680,25 +680,22 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->sort_raw = pr->dalloc<Fr>((size_t)2 * L * n);
     pr->sort_out = pr->dalloc<Fr>((size_t)2 * L * n);
     pr->rep_scratch = pr->dalloc<uint32_t>((size_t)L * n);
-    pr->err = pr->dalloc<uint32_t>(4);
     pr->h = pr->dalloc<Fr>(ne);
     pr->aux_ext = pr->dalloc<Fr>((size_t)2 * ne);
     pr->hx = pr->dalloc<Fr>((size_t)2 * n);          // h(X) folded at x, then the random polynomial: one NTT batch
     pr->rand_poly = pr->hx + n;
     pr->lag2 = pr->dalloc<Fr>((size_t)2 * n);
     pr->pw = pr->dalloc<Fr>((size_t)MAX_POINTS * n);
-    pr->points = pr->dalloc<Fr>(MAX_POINTS);
     pr->jobs = pr->dalloc<EvalJob>(512);
     pr->fsets = pr->dalloc<Fr>((size_t)MAX_SETS * n);
     pr->pdiff = pr->dalloc<Fr>((size_t)MAX_POINTS * n);
     pr->dinv = pr->dalloc<Fr>((size_t)MAX_POINTS * n);
     pr->wvals = pr->dalloc<Fr>((size_t)2 * n);
     pr->mdiff = pr->dalloc<Fr>((size_t)2 * n);
-    pr->lin = pr->dalloc<LincombArgs>(MAX_SETS);
-    pr->shp_args = pr->dalloc<ShplonkArgs>(1);
-    pr->blinds = pr->dalloc<Fr>((size_t)(S + L + 2 * L) * (P.bf + 1) + 64);
+    static_assert(sizeof(ShplonkArgs) % 8 == 0, "LincombArgs follows ShplonkArgs in one arena");
+    pr->shp_args = (ShplonkArgs*)pr->dalloc<uint8_t>(sizeof(ShplonkArgs) + MAX_SETS * sizeof(LincombArgs));
+    pr->lin = (LincombArgs*)((uint8_t*)pr->shp_args + sizeof(ShplonkArgs));
     pr->ntt_tmp = pr->dalloc<Fr>((size_t)(NV + 1) * ne);
-    pr->key = pr->dalloc<uint32_t>(8);
     pr->rank = pr->dalloc<uint32_t>((size_t)2 * L * n);
     pr->stage.reserve((size_t)1 << 20);
     SHP_HIP(hipHostMalloc((void**)&pr->h_grid, (size_t)(P.num_advice + 1) * n * sizeof(Fr), hipHostMallocDefault));
@@ -883,6 +880,14 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         memcpy(sbuf, src, bytes);
         SHP_HIP(hipMemcpyAsync(dst, sbuf, bytes, hipMemcpyHostToDevice, st));
     };
+    // Small inputs that every consuming thread reads at most once (blinding values, evaluation points) are not uploaded
+    // at all: the kernel reads them from the pinned arena over the host link.  An upload is a dispatch of its own, and
+    // on a busy chip every dispatch costs its stream tens of microseconds whatever its size.
+    auto staged = [&](const void* src, size_t bytes) -> const void* {
+        void* sbuf = pr->stage_alloc(std::max<size_t>(bytes, 1));
+        memcpy(sbuf, src, bytes);
+        return sbuf;
+    };
     // commitments: `batch` columns over one basis (optionally a second job over another), through the pool's
     // combiner when this lane has one; either way the lane's stream has drained when the points are back
     auto commit = [&](shp_msm* m, const Fr* scalars, uint32_t batch, G1Affine* out, const MsmRows* rows = nullptr,
@@ -957,7 +962,6 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     if (A) SHP_HIP(hipMemcpy2DAsync(V(0) + u, pitch, grid + u, pitch, (size_t)(n - u) * sizeof(Fr), A, hipMemcpyHostToDevice, st));
     if (!instances.empty())
         SHP_HIP(hipMemcpyAsync(V(I_INST), instcol, instances.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
-    h2d(pr->key, key, 32);
     Transcript tr(pk->vk_digest);
     for (auto& v : instances) tr.common_scalar(v);
     pc.mark("witness+upload");
@@ -969,7 +973,9 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         memcpy(pr->h_rand.p, in.draws + ctr_rand, (size_t)n * sizeof(Fr));
         SHP_HIP(hipMemcpyAsync(pr->rand_poly, pr->h_rand.p, (size_t)n * sizeof(Fr), hipMemcpyHostToDevice, st));
     } else {
-        hipLaunchKernelGGL(chacha_fr_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->key, ctr_rand, n, pr->rand_poly);
+        ChaKey ck;
+        memcpy(ck.w, key, 32);
+        hipLaunchKernelGGL(chacha_fr_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, ck, ctr_rand, n, pr->rand_poly);
     }
     std::vector<G1Affine> pts(std::max<uint32_t>({A + 1, 2 * L, S + L + 1, P.degree}));
     const MsmRows adv_rows{rows_now, u, n - u};       // assigned rows + blinding rows; the rest is zero
@@ -1026,18 +1032,18 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             for (uint32_t j = 0; j < 2 * nb; j++) hb.push_back(draw());   // permuted input rows, then table rows
             ctr += 2;                                                     // two (unused) commitment blinds
         }
-        h2d(pr->blinds, hb.data(), hb.size() * sizeof(Fr));
-        SHP_HIP(hipMemsetAsync(pr->err, 0, 16, st));
+        const Fr* lk_blinds = (const Fr*)staged(hb.data(), hb.size() * sizeof(Fr));
+        uint32_t* herr = (uint32_t*)pr->stage_alloc(L * sizeof(uint32_t));   // written by the kernel, read after the commit
+        for (uint32_t l = 0; l < L; l++) herr[l] = 0;
         uint32_t nt = std::min<uint32_t>(1024, n);
         // sorted input of lookup l at sort_out[2l], sorted table at sort_out[2l+1]
         hipLaunchKernelGGL(lookup_flags_kernel, dim3(ceil_div(u, 256), L), dim3(256), 0, st, pr->sort_out, pr->sort_out + n,
                            (size_t)2 * n, u, n, pr->rank);
         hipLaunchKernelGGL(lookup_permute_kernel, dim3(L), dim3(nt), 0, st, pr->sort_out, pr->sort_out + n, (size_t)2 * n, u, n,
-                           V(I_PIN), V(I_PIN + 1), (size_t)2 * n, pr->rep_scratch, pr->rank, pr->blinds, pr->err);
-        uint32_t* herr = (uint32_t*)pr->stage_alloc(4);  // read back with the commitments (the MSM run synchronises)
-        SHP_HIP(hipMemcpyAsync(herr, pr->err, 4, hipMemcpyDeviceToHost, st));
-        commit(srs->msm_gl, V(I_PIN), 2 * L, pts.data());
-        SHP_REQUIRE(*herr == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
+                           V(I_PIN), V(I_PIN + 1), (size_t)2 * n, pr->rep_scratch, pr->rank, lk_blinds, herr);
+        commit(srs->msm_gl, V(I_PIN), 2 * L, pts.data());                 // the MSM run synchronises the stream
+        for (uint32_t l = 0; l < L; l++)
+            SHP_REQUIRE(herr[l] == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
         for (uint32_t i = 0; i < 2 * L; i++) tr.write_point(pts[i].x, pts[i].y);
     }
     pc.mark("lookup");
@@ -1062,12 +1068,12 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         for (uint32_t j = 0; j < bf; j++) hb.push_back(draw());
         ctr += 1;
     }
-    h2d(pr->blinds, hb.data(), hb.size() * sizeof(Fr));
+    const Fr* z_blinds = (const Fr*)staged(hb.data(), hb.size() * sizeof(Fr));
     pr->timers.begin(KID_GRAND_PRODUCT, st);
     if (S + L) {                                           // a plan may have neither a permutation nor a lookup
         const InvList il = product_scans(pr->num, pr->den, S + L);
         hipLaunchKernelGGL(grand_product_apply_kernel, dim3(snb, S + L), dim3(sbs), 0, st, pr->sc_pre, pr->sc_suf, sc_bpre,
-                           sc_bsuf, sc_inv, n, S, u, bf, V(I_PZ), (size_t)n, pr->blinds, il);
+                           sc_bsuf, sc_inv, n, S, u, bf, V(I_PZ), (size_t)n, z_blinds, il);
     }
     pr->timers.end(st);
     SHP_REQUIRE(ctr == ctr_rand, SHP_ERR_INTERNAL, "prove: blinding stream position of the random polynomial");
@@ -1149,11 +1155,11 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         pt_index[r] = (uint32_t)i;
         points[i] = x * (r >= 0 ? Fr::pow_u64(pk->omega, (uint64_t)r) : Fr::pow_u64(pk->omega_inv, (uint64_t)(-r)));
     }
-    h2d(pr->points, points.data(), points.size() * sizeof(Fr));
+    const Fr* d_points = (const Fr*)staged(points.data(), points.size() * sizeof(Fr));
     {
         uint32_t per = 1;                                   // one power per thread: the chain is the exponentiation alone
         hipLaunchKernelGGL(powers_kernel, dim3(ceil_div(ceil_div(n, per), 256), (uint32_t)points.size()), dim3(256), 0, st,
-                           pr->points, n, per, pr->pw);
+                           d_points, n, per, pr->pw);
     }
     const Fr xn = Fr::pow_u64(x, n);
     hipLaunchKernelGGL(combine_pieces_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, hp, n, npieces, xn, pr->hx);
@@ -1192,7 +1198,10 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     const size_t n_proof_evals = jobs.size();
     add_job({7, 0}, 0);
     SHP_REQUIRE(jobs.size() <= 512, SHP_ERR_INVALID_ARG, "prove: too many evaluations");
-    h2d(pr->jobs, jobs.data(), jobs.size() * sizeof(EvalJob));
+    if (!pr->jobs_uploaded) {                               // coefficient buffers and point indices never change
+        h2d(pr->jobs, jobs.data(), jobs.size() * sizeof(EvalJob));
+        pr->jobs_uploaded = true;
+    }
     // the evaluations land in the pinned arena directly (one store per job over PCIe, no copy dispatch)
     Fr* const evals = (Fr*)pr->stage_alloc(jobs.size() * sizeof(Fr));
     hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)jobs.size()), dim3(EVAL_THREADS), 0, st, pr->jobs, pr->pw, n, evals);
@@ -1250,11 +1259,15 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         nu_pow = nu_pow * nu;
     }
     sa.f = pr->fsets; sa.dinv = pr->dinv; sa.omegas = pk->omegas;
-    h2d(pr->lin, lin.data(), lin.size() * sizeof(LincombArgs));
-    h2d(pr->shp_args, &sa, sizeof(sa));
+    {                                                       // both argument blocks in one upload
+        uint8_t* blk = (uint8_t*)pr->stage_alloc(sizeof(sa) + lin.size() * sizeof(LincombArgs));
+        memcpy(blk, &sa, sizeof(sa));
+        memcpy(blk + sizeof(sa), lin.data(), lin.size() * sizeof(LincombArgs));
+        SHP_HIP(hipMemcpyAsync(pr->shp_args, blk, sizeof(sa) + lin.size() * sizeof(LincombArgs), hipMemcpyHostToDevice, st));
+    }
     hipLaunchKernelGGL(lincomb_kernel, dim3(ceil_div(n, 256), (uint32_t)sets.size()), dim3(256), 0, st, pr->lin, n, pr->fsets);
     hipLaunchKernelGGL(point_diff_kernel, dim3(ceil_div(n, 256), (uint32_t)points.size()), dim3(256), 0, st, pk->omegas,
-                       pr->points, n, pr->pdiff);
+                       d_points, n, pr->pdiff);
     batch_invert(pr->pdiff, pr->dinv, (uint32_t)points.size());
     hipLaunchKernelGGL(shplonk_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals);
     commit(srs->msm_gl, pr->wvals, 1, pts.data());
@@ -1285,8 +1298,8 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     sa.w = pr->wvals;
     sa.minv = pr->mdiff + n;
     h2d(pr->shp_args, &sa, sizeof(sa));
-    h2d(pr->points, &mu, sizeof(Fr));
-    hipLaunchKernelGGL(point_diff_kernel, dim3(ceil_div(n, 256), 1), dim3(256), 0, st, pk->omegas, pr->points, n, pr->mdiff);
+    const Fr* d_mu = (const Fr*)staged(&mu, sizeof(Fr));
+    hipLaunchKernelGGL(point_diff_kernel, dim3(ceil_div(n, 256), 1), dim3(256), 0, st, pk->omegas, d_mu, n, pr->mdiff);
     batch_invert(pr->mdiff, pr->mdiff + n, 1);
     hipLaunchKernelGGL(shplonk_wp_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals + n);
     commit(srs->msm_gl, pr->wvals + n, 1, pts.data());

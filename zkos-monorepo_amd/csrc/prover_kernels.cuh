@@ -171,12 +171,13 @@ __global__ void zero_rows_kernel(Fr* cols, size_t stride, uint32_t r0, uint32_t 
 }
 
 // ------------------------------------------------------------------ blinding stream
-__global__ void chacha_fr_kernel(const uint32_t* key8, uint64_t counter0, uint32_t count, Fr* out) {
+struct ChaKey { uint32_t w[8]; };     // by value in the kernel arguments: no upload dispatch for 32 bytes
+__global__ void chacha_fr_kernel(ChaKey key8, uint64_t counter0, uint32_t count, Fr* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     uint32_t key[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) key[j] = key8[j];
+    for (int j = 0; j < 8; j++) key[j] = key8.w[j];
     st(out + i, fr_draw(key, counter0 + i));
 }
 
@@ -569,7 +570,8 @@ __global__ __launch_bounds__(256) void lookup_flags_kernel(const Fr* a_all, cons
 }
 
 // a = sorted input (raw), tb = sorted table (raw); writes permuted input / table (Montgomery)
-// rows [0,u) and the blinding rows [u,n) of both; err[0] != 0 when the input is not in the table.
+// rows [0,u) and the blinding rows [u,n) of both; err[l] != 0 when the input of lookup l is not in the table (one plain
+// store per workgroup: `err` and `blinds` may live in pinned host memory, read and written over the host link).
 // One workgroup per lookup: only prefix sums over the flags and the scatter are left here.
 __global__ __launch_bounds__(1024) void lookup_permute_kernel(const Fr* a_all, const Fr* tb_all, size_t sstride, uint32_t u,
                                                               uint32_t n, Fr* pin_all, Fr* ptab_all, size_t pstride,
@@ -592,11 +594,11 @@ __global__ __launch_bounds__(1024) void lookup_permute_kernel(const Fr* a_all, c
         bad += (f >> 1) & 1u;
         nkeep += (f >> 2) & 1u;
     }
-    if (bad) atomicAdd(err, bad);
+    const int any_bad = __syncthreads_or(bad != 0);
     uint32_t tot_rep, tot_keep;
     uint32_t rep_off = block_scan_u32_excl(nrep, sh, t, nt, &tot_rep);
     uint32_t keep_off = block_scan_u32_excl(nkeep, sh, t, nt, &tot_keep);
-    if (t == 0 && tot_rep != tot_keep) atomicAdd(err, 1u);
+    if (t == 0) err[l] = (any_bad ? 1u : 0u) | (tot_rep != tot_keep ? 2u : 0u);
     // list the repeated rows; write first occurrences
     uint32_t q = rep_off;
     for (uint32_t i = r0; i < r1; i++) {
