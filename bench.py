@@ -81,6 +81,15 @@ def latest_profile(suffix):
     return os.path.join(d, c[-1]) if c else None
 
 
+def by_kernel(table, family):
+    """entry of a per-kernel summary for a kernel family: the summaries key template instances by their full name
+    (`msm_direct_kernel<true>`), the library's event clock by family (`msm_direct`)"""
+    for key, val in table.items():
+        if key.split("<")[0] == family + "_kernel":
+            return val
+    return None
+
+
 def spawn_ranks(n):
     """`--gpus N` outside torchrun: start the N-rank launch as a child process (this process has not touched a GPU)"""
     import socket
@@ -302,7 +311,7 @@ def main():
     f_traffic = latest_profile("pmc_traffic_bench.json")
     if f_traffic:
         pmc = json.load(open(f_traffic))
-        ent = pmc.get(name + "_kernel")
+        ent = by_kernel(pmc, name)
         if ent:
             traffic = ent["fetch_bytes_per_launch_x2corr"] + ent["write_bytes_per_launch"]
             traffic_src = {"file": os.path.relpath(f_traffic, ROOT), "stale": pmc.get("_kernel_source_id") != src_id}
@@ -312,7 +321,7 @@ def main():
     if f_stats:
         import csv
         for row in csv.DictReader(open(f_stats)):
-            if row["Name"].split("(")[0].replace("shp::", "").replace("void ", "") == name + "_kernel":
+            if row["Name"].split("(")[0].replace("shp::", "").replace("void ", "").split("<")[0] == name + "_kernel":
                 rocprof_avg_us = float(row["AverageNs"]) * 1e-3
     # VALU issue: wave-instructions per proof (whole proof and the dominant kernel alone) from the committed PMC pass
     # (rocprofv3 --pmc SQ_INSTS_VALU over tools/prove_loop.py --throughput): 4 cycles each on one of 1024 SIMDs at 2.4 GHz
@@ -325,7 +334,7 @@ def main():
         wi = pv["valu_wave_instructions_per_proof"]
         achieved = wi * rate
         frac = achieved / VALU_PEAK
-        wk = pv.get("per_kernel", {}).get(name + "_kernel")
+        wk = by_kernel(pv.get("per_kernel", {}), name)
         valu = {"wave_instructions_per_proof": wi, "ideal_us_per_proof": 1e6 * wi / VALU_PEAK,
                 "source": os.path.relpath(f_valu, ROOT), "stale": pv.get("_kernel_source_id") != src_id}
         if wk and alone_avg_us and launches_per_proof:

@@ -85,28 +85,13 @@ constexpr L9 kp_spread(uint32_t K, int64_t S = 1) {
     for (int i = 0; i < 9; i++) r.l[i] = (uint32_t)t[i];
     return r;
 }
-struct L14 { uint32_t l[14]; };
-constexpr L14 kp_tops() {                                  // top limb of the normalised K p, K = 0..13
-    const L9 p = split29(modulus());
-    L14 r{};
-    for (uint32_t K = 0; K < 14; K++) {
-        uint64_t carry = 0, top = 0;
-        for (int i = 0; i < 9; i++) {
-            const uint64_t acc = (uint64_t)K * p.l[i] + carry;
-            top = acc;
-            carry = acc >> 29;
-        }
-        r.l[K] = (uint32_t)top;
-    }
-    return r;
-}
 
 constexpr L9 P29 = split29(modulus());
 constexpr uint32_t PINV29 = FqParams::INV & M29;           // -p^-1 mod 2^29
+constexpr uint32_t PPOSINV29 = (0u - FqParams::INV) & M29; // p^-1 mod 2^29
 constexpr L9 ONE = split29(pow2_mod_p(261));               // Montgomery one for R = 2^261
 constexpr L9 C266 = split29(pow2_mod_p(266));              // Montgomery-2^256 limbs (no shift) -> Montgomery-2^261, reduced
 constexpr L9 C256 = split29(pow2_mod_p(256));              // Montgomery-2^261 -> Montgomery-2^256
-constexpr L14 KP_TOP = kp_tops();
 constexpr L9 KP3 = kp_spread(3), KP6 = kp_spread(6), KP8W = kp_spread(8, 4), KP11 = kp_spread(11);
 }  // namespace f29
 
@@ -257,8 +242,8 @@ SHP_HD G1X29 from_g1x(const G1X& p) {
 
 // acc += (qx, qy), an affine point that is not the identity, given in the 8 x 32 Montgomery-2^256 form of the tables
 // (madd-2008-s, 8 products + 2 squarings).  The doubling / opposite-point case (u2 = x1) cannot be seen on lazy values
-// without a full reduction; it needs P = u2 - x1 + 11 p to be a multiple of p, whose top limb is one of 14 known values:
-// lanes that match (about one in 2^22 otherwise) take the exact 8 x 32 path.
+// without a full reduction; it needs P = u2 - x1 + 11 p to be one of the 14 multiples of p below 13.5 p: lanes whose low
+// limb says so (about one in 2^25 otherwise) take the exact 8 x 32 path.
 SHP_HD void g1_madd29(G1X29& acc, const Fq& qx, const Fq& qy) {
     if (acc.inf) {
         acc.x = from_fq_reduced(qx);
@@ -271,9 +256,9 @@ SHP_HD void g1_madd29(G1X29& acc, const Fq& qx, const Fq& qy) {
     const Fq29 x2 = split29_dev<5>(qx), y2 = split29_dev<5>(qy);          // < 32 p
     const Fq29 u2 = mul29(x2, acc.zz), s2 = mul29(y2, acc.zzz);
     const Fq29 P = sub29(u2, acc.x, f29::KP11);                           // < 13.5 p
-    bool suspicious = false;
-#pragma unroll
-    for (int k = 0; k < 14; k++) suspicious |= P.l[8] == f29::KP_TOP.l[k];
+    // P = K p (K < 14) has the low limb K p mod 2^29, so K = l[0] p^-1 mod 2^29: anything else gives a value >= 14
+    // except once in 2^29 / 14
+    const bool suspicious = ((P.l[0] * f29::PPOSINV29) & M29) < 14u;
     if (suspicious) {                                                      // rare: exact arithmetic on canonical values
         acc = from_g1x(g1_madd(to_g1x(acc), qx, qy));
         return;

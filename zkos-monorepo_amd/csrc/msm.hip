@@ -564,6 +564,10 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
     const uint32_t q = t >> 2, j = t & 3;
     for (uint32_t m = m0; m >= 1; m >>= 1) {
         const bool act = t < 4 * m;
+        // A wave none of whose lanes takes part still meets the barriers but skips the products (the branch is uniform
+        // per wave: the whole wave jumps).  From 32 additions down that is most of the workgroup; executed by all four
+        // waves the seven levels were a quarter of the vector instructions of a 20-window launch.
+        const bool wave_act = (t & ~63u) < 4 * m;
         const uint32_t a = q, b = q + m;
         Fq mine = Fq::zero(), keep = Fq::zero();
         // R1: u1 | s1 | u2 | s2
@@ -572,7 +576,7 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
             A1 = ldc(j & 1, (j & 2) ? b : a);                    // x or y of P (lanes 0,1) / of Q (lanes 2,3)
             B1 = ldc(2 + (j & 1), (j & 2) ? a : b);              // zz or zzz of the OTHER point
         }
-        mine = A1 * B1;
+        if (wave_act) mine = A1 * B1;
         if (act) sts(V_U1 + j, q, mine);
         __syncthreads();
         // Every round is ONE product executed by all four lanes on lane-selected operands: the
@@ -593,7 +597,7 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
                 B2 = ldc(j, b);
             }
         }
-        keep = A2 * B2;                                          // pp | rr2 | zz12 | zzz12
+        if (wave_act) keep = A2 * B2;                                          // pp | rr2 | zz12 | zzz12
         if (act && j < 2) sts(j == 0 ? V_PP : V_RR2, q, keep);
         __syncthreads();
         // R3: qq = u1 pp | - | zz3 = zz12 pp | ppp = pp_ pp
@@ -603,7 +607,8 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
             A3 = j == 0 ? mine : keep;                           // lane 0: u1; lane 2: zz12; (lane 1: unused)
             if (j == 3) A3 = lds(V_PPU, q);
         }
-        const Fq r3 = A3 * B3;                                   // qq | - | zz3 | ppp
+        Fq r3 = Fq::zero();
+        if (wave_act) r3 = A3 * B3;                                   // qq | - | zz3 | ppp
         if (act && j == 3) sts(V_PPP, q, r3);
         __syncthreads();
         // R4: x3, t2 = rr (qq - x3) | t1 = s1 ppp | - | zzz3 = zzz12 ppp
@@ -621,7 +626,8 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
                 B4 = r3;                                         // ppp
             }
         }
-        const Fq r4 = A4 * B4;                                   // t2 | t1 | - | zzz3
+        Fq r4 = Fq::zero();
+        if (wave_act) r4 = A4 * B4;                                   // t2 | t1 | - | zzz3
         if (act && j == 0) sts(V_U2, q, r4);                     // t2 (the u2 slot is free by now)
         if (j == 3) out = r4;
         __syncthreads();
@@ -755,7 +761,7 @@ static uint32_t pick_window(size_t n) {
 static double direct_budget_gib() {
     const char* e = getenv("SHP_MSM_TABLE_GB");
     if (e && *e) return atof(e);
-    return 48.0;       // k = 13: c = 13, 43 GB per basis (measured 869 vs 839 proofs/s at the 24 GB / c = 12 point)
+    return 84.0;       // k = 13: c = 14, 82 GB per basis, 19 windows (c = 13: 43 GB, 20 windows, -1.5 % proofs/s; c = 12: -5 %)
 }
 
 static uint32_t direct_windows(uint32_t c) {
