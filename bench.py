@@ -52,7 +52,7 @@ TAU = 0x2B6F1C0A94D3E5F7081A2B3C4D5E6F70_13
 
 
 def shard(total, rank, world):
-    """contiguous block partition of `total` independent proofs"""
+    """contiguous block partition of `total` independent proofs: ranks share no data, so a shard is a range"""
     base, rem = divmod(total, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--lanes", type=int, default=32, help="concurrent proving lanes (streams) per GPU")
     ap.add_argument("--proofs-per-lane", type=int, default=4, help="proofs each lane produces back to back in one step")
-    ap.add_argument("--latency-proofs", type=int, default=100, help="single-lane proofs timed for p50 (SURVEY 8d config 2: 100 runs)")
+    ap.add_argument("--latency-proofs", type=int, default=100, help="single-lane proofs timed for p50 (the metric's latency half: 100 runs)")
     ap.add_argument("--cpu-proofs", type=int, default=3, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--batch", type=int, default=0, help="strong-scaling mode: one step = this many distinct proofs sharded "
                                                          "over the ranks (BASELINE config 3: --batch 1024 --gpus 8)")

@@ -1,5 +1,5 @@
 // A host program with no Python and no torch in it: the C ABI of include/shielder_hip.h used the way
-// the reference's Rust front-ends would use it (INTEGRATION.md) -- load a circuit plan, build the SRS
+// the reference's Rust front-ends would use it -- load a circuit plan, build the SRS
 // and the key, prove a batch through the proving pool, verify every proof, print one JSON line.
 //
 //   shp_cli <plan.bin> <witnesses.bin> <k> <tau hex> <lanes> [proofs_out.bin]

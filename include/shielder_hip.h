@@ -11,7 +11,7 @@
  *   Params::{commit, commit_lagrange}  (exercised at lib.rs:247-264)
  *   poseidon::off_circuit::hash        /root/reference/crates/shielder_bindings/src/hash.rs:17-26
  *
- * Conventions (SURVEY.md section 8b):
+ * Conventions:
  *   - every function returns int32 status (SHP_OK = 0); nothing unwinds across the ABI;
  *     shp_last_error() returns the message of the calling thread's last failure;
  *   - Fr / Fq cross as 32 bytes: 4 x uint64 little-endian limbs in MONTGOMERY form
@@ -193,7 +193,7 @@ int32_t shp_srs_commit(shp_srs* srs, int32_t basis, const void* d_polys, uint32_
 /* ---- proving key and prover ---------------------------------------------------------- */
 /* generate_keys_with_min_k + unmarshall_pk (/root/reference/crates/shielder_bindings/build.rs:19-32,
  * src/circuits/mod.rs:38-46): builds the device-resident proving key of the circuit described by
- * `plan` (circuit plan v1: DESIGN.md, zkos-monorepo_amd/circuits/builder.py) over `srs`, which must
+ * `plan` (circuit plan v1: layout in zkos-monorepo_amd/circuits/builder.py) over `srs`, which must
  * outlive the key.  Fixed/permutation polynomials, their extended cosets and commitments are
  * computed on the GPU. */
 int32_t shp_keygen(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan, size_t plan_len, shp_pk** out);
@@ -217,7 +217,7 @@ int32_t shp_generate_keys_with_min_k(shp_ctx* ctx, const shp_srs* full_srs, cons
  * permutation columns, gate and lookup expressions as nodes, fixed values, copy constraints or the finished permutation
  * mapping, optionally a witness program -- becomes the circuit plan shp_keygen takes: degree and blinding factors,
  * merged subexpressions, the interpreter programs with their slot allocation, the permutation mapping.  Byte layout of
- * the description: zkos-monorepo_amd/csrc/plancompile.hip; a Rust emitter for it: INTEGRATION.md.  Host only;
+ * the description: zkos-monorepo_amd/csrc/plancompile.hip; Host only;
  * out == NULL sizes. */
 int32_t shp_plan_compile(const uint8_t* description, size_t len, uint8_t* out, size_t out_cap, size_t* out_len);
 /* the smallest k with 2^k - (blinding_factors + 1) rows for everything the plan places on rows (host only) */
@@ -249,7 +249,7 @@ int32_t shp_prover_destroy(shp_prover* p);
  *                  witness-input order (for the withdraw plan: the argument order of
  *                  WithdrawCircuit::prove, src/circuits/withdraw.rs:88-114); SHP_ERR_FORMAT if >= r
  *   seed           32 bytes keying the ChaCha20 blinding stream (the reference's `rng`); Fr draw i is
- *                  from_u512(ChaCha20(seed, block i)), consumed in the order documented in DESIGN.md
+ *                  from_u512(ChaCha20(seed, block i)), consumed in the order given at shp_prove_with_randomness
  *   proof_out      caller buffer (capacity proof_cap, >= shp_pk_info proof_len); *proof_len is set
  *   instances_le32 optional: the public inputs (serialize_public_input), 32-byte LE canonical each */
 int32_t shp_prove(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, const uint8_t seed[32],
@@ -269,7 +269,7 @@ int32_t shp_prove_with_randomness(shp_prover* p, const uint8_t* witness_le32, si
                                   uint8_t* instances_le32, size_t instances_cap);
 /* generate_proof for a circuit the CALLER synthesised: the reference hands create_proof an `impl Circuit<Fr>`
  * (/root/reference/crates/shielder_bindings/src/circuits/mod.rs:103-111) whose `synthesize` fills the advice columns.  A
- * Rust integrator runs that synthesis into a collector and passes the result:
+ * Rust integrator runs that synthesis into a collector (an `Assignment` that records assign_advice) and passes the result:
  *   advice         n_columns x n_rows field elements, column-major, Montgomery limbs, host memory; n_columns = the plan's
  *                  advice columns, n_rows = 2^k.  Rows >= 2^k - (blinding_factors + 1) are ignored (blinded here).
  *   assigned_rows  rows [assigned_rows, usable) of every column are zero and are not read (0 = all usable rows)
@@ -318,7 +318,7 @@ int32_t shp_prover_profile_read(shp_prover* p, uint32_t index, const char** name
 /* Host-side phase clock of the LAST proof of this lane (shp_prover_profile(p, 1), or 2 = the phase clock alone,
  * without HIP events in the stream): phase `index` = name and wall time in
  * microseconds, in proof order (witness program, upload, advice commitments, lookups, grand products, quotient,
- * evaluations, W, W'); SHP_ERR_INVALID_ARG past the last phase.  The per-phase split of SURVEY.md 8d config 2. */
+ * evaluations, W, W'); SHP_ERR_INVALID_ARG past the last phase.  The per-phase split of a lone proof's latency. */
 int32_t shp_prover_phase_read(shp_prover* p, uint32_t index, const char** name, double* us);
 /* poseidon::off_circuit::hash on the host (shielder_bindings/src/hash.rs:17-26): 32-byte LE canonical */
 int32_t shp_poseidon2_hash_host(const uint8_t* inputs_le32, uint32_t arity, uint8_t out_le32[32]);
@@ -368,7 +368,7 @@ int32_t shp_pool_stats(const shp_pool* p, uint64_t* proofs_done, uint64_t* queue
 
 /* ---- diagnostics ------------------------------------------------------------------- */
 /* sustained Fr Montgomery products per second with every CU busy: the integer-ALU ceiling that
- * bounds MSM and NTT on this part (DESIGN.md "Rooflines") */
+ * bounds MSM and NTT on this part: a 254-bit Montgomery product is ~300 32-bit instructions and HBM is never the limit */
 int32_t shp_diag_fr_mul_rate(shp_ctx* ctx, uint32_t iters, double* muls_per_sec);
 
 #ifdef __cplusplus

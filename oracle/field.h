@@ -193,7 +193,7 @@ static inline int fp_from_be32(fe *r, const uint8_t b[32], const fparams *P) {
     return fp_from_le32(r, le, P);
 }
 /* 64 uniform bytes (LE) -> field element: d0*R^2 + d1*R^3 in Montgomery arithmetic,
- * halo2curves' from_u512 (SURVEY Appendix B). */
+ * halo2curves' from_u512. */
 static inline void fp_from_u512(fe *r, const uint8_t b[64], const fparams *P) {
     fe d0, d1, r2, r3, t0, t1;
     memcpy(d0.l, b, 32);

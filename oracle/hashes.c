@@ -5,7 +5,7 @@
  *    verifier pins (/root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:105-124);
  *    KATs: /root/reference/crates/shielder-account/src/secrets.rs:75-106.
  *  - ChaCha20 block function (RFC 8439 state layout, 64-bit counter in words 12..13):
- *    the blinding-randomness expander of this build's ABI (DESIGN.md "Randomness").
+ *    the blinding-randomness expander of this build's ABI (Fr draw i = from_u512 of block i).
  *  - Poseidon2 permutation t=8, alpha=7, R_F=8, R_P=48 over BN254 Fr and the
  *    arity-N sponge `hash` with capacity N*2^64, restating the round structure of
  *    /root/reference/poseidon2-solidity/generate_t8.py:474-588.
@@ -157,7 +157,8 @@ void orc_poseidon2_permute(fe s[8]) {
 }
 
 /* hash of `arity` (1..7) inputs: state = [x0..x_{arity-1}, 0.., arity * 2^64]
- * (generate_t8.py:521-531 for arity 7; SURVEY.md a6 for arity < 7), output lane 0 */
+ * (generate_t8.py:521-531 for arity 7; for arity < 7 the same rule is ASSUMED -- halo2 poseidon's ConstantLength<N> padding --
+ * and pinned by no reference vector), output lane 0 */
 void orc_poseidon2_hash(const fe *in, int arity, fe *out) {
     fe s[8];
     memset(s, 0, sizeof(s));

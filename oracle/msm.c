@@ -2,7 +2,7 @@
  * oracle/msm.c — TEST INFRASTRUCTURE (CPU oracle), not product code.
  *
  * Multi-scalar multiplication restating halo2curves 0.6.1 `best_multiexp` /
- * `multiexp_serial` (un-vendored; SURVEY.md Appendix D): window c = 1 | 3 | ceil(ln m),
+ * `multiexp_serial` (un-vendored): window c = 1 | 3 | ceil(ln m),
  * segments = 256/c + 1 processed high to low with c doublings between, 2^c - 1
  * buckets, running-sum reduction; the point range is split over the threads and the
  * per-chunk results added.  No signed digits, no GLV.  The result is a group

@@ -2,7 +2,7 @@
  * oracle/oracle.h — TEST INFRASTRUCTURE: the CPU oracle's exported surface.
  *
  * A plain-C restatement of the algorithms on the Shielder proving path
- * (SURVEY.md section 8a).  It exists to CHECK the HIP path (tests/, smoke()) and
+ * (SRS ingest, MSM, NTT, Poseidon2, Keccak transcript, the PLONK prover and verifier).  It exists to CHECK the HIP path (tests/, smoke()) and
  * to be TIMED as the CPU baseline (bench.py cpu_baseline).  Nothing in the
  * product (zkos-monorepo_amd/, include/) may include, link or call it.
  *
@@ -10,7 +10,7 @@
  * fixtures the reference holds (ptau/RawBytes SRS incl. g_lagrange, Poseidon2
  * parameter set and generated on-chain code, Keccak KATs, delta/omega literals);
  * whole-proof bytes are UNPINNED (the reference has no golden proof and its
- * prover crates are not vendored: SURVEY.md section 8c).
+ * prover crates are not vendored).
  */
 #ifndef ORACLE_H
 #define ORACLE_H

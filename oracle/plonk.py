@@ -4,7 +4,7 @@ A restatement of halo2_proofs v0.3.0 `keygen_pk` / `create_proof` / `verify_proo
 KZG-SHPLONK (Bdfg21) multi-open and the EVM Keccak transcript, for a circuit given as a
 *circuit plan* (zkos-monorepo_amd/circuits/builder.py).  halo2_proofs is an un-vendored git
 dependency of the reference (Cargo.lock:2332-2334, tag v0.3.0); its algorithm is restated from
-the published design (SURVEY.md Appendix B/D) and anchored on what the reference itself pins:
+the published design and anchored on what the reference itself pins:
   proof layout / transcript rules / challenge order   crates/halo2-verifier/src/lib/codegen/util.rs:133-245,
                                                       templates/Halo2Verifier.sol:89-124, 247-307
   quotient identity (gates, permutation, lookups)     codegen/evaluator.rs:45-223, codegen.rs:237-254
@@ -298,7 +298,7 @@ def _lagrange_column(n, sparse):
 
 
 def keygen(plan: Plan, srs, transcript_repr=None) -> ProvingKey:
-    """keygen_vk + keygen_pk (SURVEY.md row a4): fixed/sigma polys, cosets, commitments, l0/l_last/l_active.
+    """keygen_vk + keygen_pk: fixed/sigma polys, cosets, commitments, l0/l_last/l_active.
     transcript_repr (int): halo2's vk.transcript_repr(), absorbed first by the verifier (Halo2Verifier.sol:247-248), for
     callers that hold the halo2 VerifyingKey; None = the build's own digest over plan and commitments"""
     assert srs.k == plan.k
@@ -443,8 +443,8 @@ def lagrange_interp(xs, ys):
 
 # ------------------------------------------------------------------------------ prover
 def prove(pk: ProvingKey, srs, inputs, seed: bytes, return_trace=False, randomness=None, assigned=None):
-    """create_proof: phases P0..P13. `seed` keys the
-    ChaCha20 blinding stream; draws are consumed in the documented order.
+    """create_proof: phases P0..P13 (witness, advice, lookups, grand products, quotient, evaluations, SHPLONK). `seed` keys the
+    ChaCha20 blinding stream; draws are consumed in the order include/shielder_hip.h gives at shp_prove_with_randomness.
     randomness: (count, 4) Montgomery array of pre-drawn Fr::random values used INSTEAD of the seed's stream (the
     reference's `rng` handed over as its draws); assigned: (advice_ints[col][row], instances) from the caller's own
     synthesis instead of the plan's witness program."""
@@ -741,7 +741,7 @@ def proof_layout(plan):
 
 
 def verify(pk: ProvingKey, proof: bytes, instances, tau=None, g2=None, s_g2=None, trace=None):
-    """verify_proof restated from Halo2Verifier.sol + codegen (SURVEY.md Appendix C).  The final
+    """verify_proof restated from Halo2Verifier.sol + codegen.  The final
     check e(lhs, g2) = e(W', s g2) is done with the trapdoor when `tau` is known (synthetic SRS)
     or with the BN254 pairing (oracle/pairing.py) when g2 / s_g2 are given.
     trace (dict, optional): receives what the reference's contract keeps in its named memory words

@@ -2,7 +2,7 @@
  * oracle/poly.c — TEST INFRASTRUCTURE (CPU oracle), not product code.
  *
  * Evaluation-domain arithmetic restating halo2_proofs v0.3.0's EvaluationDomain /
- * best_fft (un-vendored; Cargo.lock:2332-2334; conventions in SURVEY.md Appendix D,
+ * best_fft (un-vendored; Cargo.lock:2332-2334;
  * constants pinned by /root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:475
  * (delta) and by resources/ppot_0080_11_raw's g_lagrange (omega, direction)):
  *   ROOT_OF_UNITY = 7^((r-1)/2^28), omega_k = ROOT^(2^(28-k)), delta = 7^(2^28),

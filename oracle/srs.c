@@ -127,8 +127,8 @@ static void fixed_base_mul_many(const fe *scalars, size_t n, g1a *out) {
     free(ta);
 }
 
-/* Synthetic SRS with a KNOWN trapdoor (stand-in for the absent ppot_0080_13.ptau,
- * SURVEY.md section 8d config 2): g[i] = tau^i G; g_lagrange[i] = L_i(tau) G with
+/* Synthetic SRS with a KNOWN trapdoor (stand-in for the ppot_0080_13.ptau the
+ * reference downloads and does not ship): g[i] = tau^i G; g_lagrange[i] = L_i(tau) G with
  * L_i(tau) = (tau^n - 1)/n * omega^i / (tau - omega^i).  g2/s_g2 are not produced
  * (left zero): proofs over a synthetic SRS are checked with the trapdoor. */
 void orc_srs_synthetic(uint32_t k, const fe *tau, orc_srs *out) {

@@ -1,7 +1,7 @@
 /*
  * oracle/vec.c — TEST INFRASTRUCTURE (CPU oracle), not product code.
  * Element-wise Fr vector primitives (OpenMP) used by oracle/plonk.py, the restatement of
- * halo2_proofs v0.3.0 create_proof (SURVEY.md Appendix B/D): the Python side only sequences
+ * halo2_proofs v0.3.0 create_proof: the Python side only sequences
  * them, every field operation runs here.
  */
 #include "oracle.h"

@@ -1,4 +1,4 @@
-"""CPU: the oracle against every golden vector the reference holds for the path (SURVEY.md 8c)."""
+"""CPU: the oracle against every golden vector the reference holds for the path."""
 import json
 import random
 

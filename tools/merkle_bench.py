@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Rate of the Merkle witness service (SURVEY.md 8f row 4): arity-7 Poseidon2 tree of height 13 over N notes built on
+"""Rate of the Merkle witness service: arity-7 Poseidon2 tree of height 13 over N notes built on
 the GPU, then getMerklePath for batches of leaves.   python tools/merkle_bench.py [--leaves 1000000] [--queries 4096]"""
 import argparse, ctypes as C, importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -3,7 +3,7 @@
 
   python tools/microbench.py [--ntt 20 22 24] [--msm 16 20] [--reps 5]
 Reports ms per launch group, algorithmic bytes / time vs the 8 TB/s HBM roofline (64*N for the
-NTT, 96*N for the MSM: SURVEY.md section 8d) and the measured Fr-mul ceiling.
+NTT, 96*N for the MSM: a 32-byte scalar and a 64-byte affine base per term) and the measured Fr-mul ceiling.
 """
 import argparse, importlib, json, os, sys, time
 import numpy as np

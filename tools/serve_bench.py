@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""End-to-end rate of the serve path (SURVEY.md 8f row 2): Withdraw requests in the TEE wire format
+"""End-to-end rate of the serve path: Withdraw requests in the TEE wire format
 (4-byte length + JSON, zkos-monorepo_amd/serve.py) over TCP -> native proving pool -> EncryptedProof responses.
    python tools/serve_bench.py [--clients 48] [--requests 20] [--lanes 16]
 Server and clients share one process (asyncio); the clients verify nothing, they count and time."""

@@ -8,7 +8,7 @@ exactly those the reference's verifier generator reads off a halo2 ConstraintSys
 (/root/reference/crates/halo2-verifier/src/lib/codegen/util.rs:42-131): k, blinding factors,
 advice/fixed/instance queries, permutation columns, gate polynomials, lookups, degree.
 
-Plan layout (little endian, version 1) -- see DESIGN.md "Circuit plan":
+Plan layout (little endian, version 1; parsed by csrc/plan.hpp):
   header (20 x u32) | advice queries | fixed queries | instance queries | permutation columns |
   constants (32 B canonical LE) | gate program | lookup programs | fixed column values (sparse) |
   permutation mapping (u32[n] per permutation column) | witness program | instance map

@@ -1,7 +1,7 @@
 """Withdraw-shaped stand-in circuit for the Shielder `WithdrawCircuit`.
 
-The real constraint system lives in the private/un-vendored zkOS-circuits crate (SURVEY.md
-section 7 "Hard parts"); this is a documented stand-in with the same witness
+The real constraint system lives in the private, un-vendored zkOS-circuits crate, which is not part of the
+reference tree; this is a documented stand-in with the same witness
 (`WithdrawProverKnowledge`, /root/reference/crates/shielder_bindings/src/circuits/withdraw.rs:88-114),
 the same 8 public inputs in the same order (withdraw.rs:18-27,
 /root/reference/contracts/Shielder.sol:679-701), the same hash (Poseidon2 t=8, arity 7), the same

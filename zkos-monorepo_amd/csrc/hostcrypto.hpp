@@ -1,6 +1,7 @@
 // Host-side Keccak-256 (EVM transcript hash, /root/reference/crates/halo2-verifier/templates/
 // Halo2Verifier.sol:105-124) and the ChaCha20 block function that expands the caller's 32-byte
-// blinding seed (DESIGN.md "Randomness"); the ChaCha block is also compiled for the device.
+// blinding seed (Fr draw i = from_u512 of ChaCha20 block i; draw order: include/shielder_hip.h at
+// shp_prove_with_randomness); the ChaCha block is also compiled for the device.
 #pragma once
 #include <stdint.h>
 #include <string.h>

@@ -1,7 +1,7 @@
 // BN254 G1 Pippenger MSM for gfx950 (fixed bases, batched scalar vectors).
 //
 // Replaces halo2curves 0.6.1 `best_multiexp` behind Params::commit / commit_lagrange
-// (exercised by the reference at
+// (every commitment of keygen and create_proof; exercised by the reference at
 // /root/reference/crates/powers-of-tau/lib.rs:247-264).  The result is a group element, so
 // after normalisation it is bit-identical to the reference's bucket method.
 //

@@ -1,7 +1,7 @@
 // Radix-2 NTT / iNTT over BN254 Fr for gfx950.
 //
 // Replaces halo2_proofs v0.3.0 EvaluationDomain::{best_fft, lagrange_to_coeff,
-// coeff_to_extended, extended_to_coeff} on the proving path (SURVEY.md section 8a rows a10/a4;
+// coeff_to_extended, extended_to_coeff} on the proving path (keygen and the quotient phase;
 // conventions pinned by /root/reference/resources/ppot_0080_11_raw's g_lagrange and the delta
 // literal at /root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:475).
 //

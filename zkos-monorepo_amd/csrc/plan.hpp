@@ -1,6 +1,6 @@
 // Circuit plan (version 1) parser: the constraint system + fixed data + witness program the
-// prover is driven by.  Layout documented in zkos-monorepo_amd/circuits/builder.py and
-// DESIGN.md; the fields are the quantities the reference's verifier generator reads off a halo2
+// prover is driven by.  Layout documented in zkos-monorepo_amd/circuits/builder.py;
+// the fields are the quantities the reference's verifier generator reads off a halo2
 // ConstraintSystem (/root/reference/crates/halo2-verifier/src/lib/codegen/util.rs:42-131).
 #pragma once
 #include <string.h>

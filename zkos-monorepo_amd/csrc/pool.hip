@@ -5,8 +5,8 @@
 // server.rs:157-195) behind a bounded task pool (tee/crates/shielder-prover-server/src/main.rs:42-45,
 // command_line_args.rs:23-28: cap 100, spawn timeout -> HTTP 504).  Here the proving key stays
 // resident in HBM (the TEE re-decodes params.bin / pk.bin on every request, server.rs:170-173), a
-// lane = one HIP stream + workspace, and shp_prove_batch is the batch entry point SURVEY.md 8b asks
-// for: `count` independent proofs sharded over the lanes of this GPU.  No CPU fallback anywhere.
+// lane = one HIP stream + workspace, and shp_prove_batch is the batch entry point:
+// `count` independent proofs sharded over the lanes of this GPU.  No CPU fallback anywhere.
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -109,7 +109,7 @@ int32_t shp_pool_create(shp_pk* pk, uint32_t lanes, uint32_t queue_cap, shp_pool
             p->lanes.push_back(pr);
         }
         // opt-in (SHP_POOL_COMBINE=1): on one MI355X the pool is not limited by the size of its MSM launches --
-        // 16 lanes lose 19 % behind the combiner's serial launches, 48 lanes only draw level (DESIGN.md section 5)
+        // 16 lanes lose 19 % behind the combiner's serial launches, 48 lanes only draw level
         const char* ce = getenv("SHP_POOL_COMBINE");
         if (lanes > 1 && ce && ce[0] == '1') {
             try {

@@ -7,8 +7,8 @@
 // i.e. halo2_proofs v0.3.0 keygen_pk / create_proof with ProverSHPLONK and the EVM Keccak
 // transcript.  Proof layout, challenge order and the identities proven are those the
 // reference's verifier generator fixes (codegen/util.rs:133-245, evaluator.rs:45-223,
-// pcs/bdfg21.rs, templates/Halo2Verifier.sol:247-307); phase order and blinding draws follow
-// SURVEY.md Appendix B.  The host only sequences phases, hashes the transcript and handles
+// pcs/bdfg21.rs, templates/Halo2Verifier.sol:247-307); phase order and blinding draws are
+// those of halo2_proofs v0.3.0 create_proof (draw order: include/shielder_hip.h at shp_prove_with_randomness).  The host only sequences phases, hashes the transcript and handles
 // a few scalars per phase; every vector operation runs in HIP kernels.
 #include <algorithm>
 #include <atomic>
@@ -332,7 +332,7 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     *out = pk.release();
 }
 
-// P1: the plan's witness program over Montgomery values (SURVEY.md row a7 `synthesize`).
+// P1: the plan's witness program over Montgomery values (the reference's `synthesize`).
 // Ops [lo, hi) with a caller-owned scratch row.
 static void run_witness_range(const PlanData& P, const std::vector<Fr>& inputs, Fr* grid /* [A][n], pinned */, Fr* scratch,
                               uint32_t lo, uint32_t hi) {

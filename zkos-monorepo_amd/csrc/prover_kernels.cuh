@@ -1,4 +1,5 @@
-// Device kernels of the PLONK prover (halo2 create_proof phases P3-P13):
+// Device kernels of the PLONK prover (halo2 create_proof from the lookup
+// permutation to the SHPLONK opening):
 // expression-program interpreter, grand products, lookup permutation, quotient terms,
 // evaluations and the evaluation-form SHPLONK quotients.  Everything is element-wise or a
 // single-workgroup scan over n <= 2^16 rows: latency-, not bandwidth-bound at k = 13, so the
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void batch_invert_apply_kernel(const 
 }
 
 // ------------------------------------------------------------------ lookup permutation
-// (halo2 lookup::prover::permute_expression_pair, SURVEY.md Appendix D) -- all on device:
+// (halo2 lookup::prover::permute_expression_pair) -- all on device:
 // rank sort of the usable rows (n^2 / 2 comparisons are cheap at n = 2^13), then flags,
 // prefix sums and binary searches in one workgroup.
 // a < b as 256-bit integers: the borrow of a - b (one carry chain, no branches)

@@ -4,7 +4,7 @@
 // Host code only (a verification is a few dozen group operations and one pairing product: ~40 ms on one
 // core, nothing for the GPU to do).  The equations are those the reference's verifier generator
 // emits (/root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:247-559,
-// src/lib/codegen/{util,evaluator,pcs}.rs, pcs/bdfg21.rs; digest in SURVEY.md Appendix C):
+// src/lib/codegen/{util,evaluator,pcs}.rs, pcs/bdfg21.rs):
 //   1. replay the Keccak transcript over the proof bytes -> theta, beta, gamma, y, x, zeta, nu, mu
 //   2. l_0, l_last, l_blind, instance evaluation at x
 //   3. fold gate / permutation / lookup expressions with y, require h(x) = numer / (x^n - 1)

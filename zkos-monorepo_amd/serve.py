@@ -8,7 +8,7 @@ Mirrors (field names, enum tagging, framing):
                                                 /root/reference/tee/crates/shielder-prover-tee/src/circuits/withdraw.rs:12-23, 64-76
   request flow (decode payload -> pub inputs -> prove -> respond)
                                                 /root/reference/tee/crates/shielder-prover-tee/src/server.rs:75-90, 128-195
-Differences, all deliberate (out of scope: AWS Nitro specifics):
+Differences, all deliberate (the AWS Nitro specifics -- vsock, ECIES, attestation -- are outside this path):
   * transport is TCP on localhost instead of vsock; * the payload is NOT ECIES-encrypted and the
   `EncryptedProof` fields carry the plain proof / public-input JSON; * `TeePublicKey` answers with
   an empty key and attestation document; * the proving key is resident in HBM and proofs go
