@@ -219,6 +219,40 @@ def test_msm_edge_cases(shp, oracle, gpu_ctx):
     m.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", [10, 13, 16])
+def test_msm_two_level_scatter_matches_oracle(shp, oracle, gpu_ctx, window, monkeypatch):
+    """the bucket method's two-level scatter (bins of 256 buckets, then buckets), forced on inputs far smaller than the
+    sizes that select it by themselves: random scalars, columns whose digits fall into one or two bins only (a slice of
+    the second level then spans many bins or a single bucket), the empty column, fewer scalars than bases"""
+    monkeypatch.setenv("SHP_MSM_TWO_LEVEL", "1")
+    n = 8192
+    osrs = oracle.srs_synthetic(13, 0xDEADBEEFCAFE1234567)
+    bases = osrs.g.copy()
+    bases[7] = 0
+    m = shp.Msm(gpu_ctx, bases, window)
+    rnd = random.Random(window)
+    cols = [
+        [rnd.randrange(R) for _ in range(n)],
+        [0] * n,
+        [1] * n,
+        [rnd.randrange(4) for _ in range(n)],
+        [R - 1 - rnd.randrange(3) for _ in range(n)],
+        [0] * (n - 1) + [98765],
+        [(rnd.randrange(1 << 20) << 200) + rnd.randrange(2) for _ in range(n)],
+    ]
+    s = oracle.fr_array([x for c in cols for x in c])
+    got = m.run(shp.to_device(s), n, len(cols))
+    for i, c in enumerate(cols):
+        assert np.array_equal(got[i], oracle.msm(bases, s.reshape(len(cols), n, 4)[i])), f"window {window} column {i}"
+    got2 = m.run(shp.to_device(s[:777]), 777, 1)
+    assert np.array_equal(got2[0], oracle.msm(bases[:777], s[:777]))
+    monkeypatch.setenv("SHP_MSM_TWO_LEVEL", "0")
+    got3 = m.run(shp.to_device(s[:n]), n, 1)
+    assert np.array_equal(got3[0], got[0])
+    m.close()
+
+
 # BASELINE configs 4 and 5 at every size they name (2^20, 2^22, 2^24) against the CPU port: the 2^24 MSM costs the port
 # about 8 s and 1 GB, the 2^24 NTT 2 s.  MICRO_LOG_NS narrows the list (e.g. MICRO_LOG_NS=20 for a quick run).
 _MICRO = [int(x) for x in __import__("os").environ.get("MICRO_LOG_NS", "20,22,24").split(",")]

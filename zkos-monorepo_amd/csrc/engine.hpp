@@ -67,6 +67,7 @@ struct MsmRows { uint32_t prefix, tail_start, tail_count; };
 struct MsmWorkspace {
     KernelTimers* timers = nullptr;
     DevBuf cnt, start, entries, pf, pl, buckets, out, wg_hist;
+    DevBuf binned, cursor;                 // two-level scatter of large MSMs: entries grouped by bucket bin, bucket write cursors
     PinnedBuf h_out, h_totals;             // G1X sums / per-MSM entry counts, read back after each run
     DevBuf done;                           // direct mode: per-MSM count of finished workgroups (zero between launches)
     size_t done_zeroed = 0;                // bytes of `done` known to be zero
@@ -78,7 +79,7 @@ struct MsmWorkspace {
     uint64_t min_waves = 0;     // direct mode: waves a launch should have before chains get longer (0 = default)
     void release() {
         cnt.release(); start.release(); entries.release(); pf.release(); pl.release(); buckets.release(); out.release();
-        wg_hist.release(); h_out.release(); h_totals.release(); segs.release(); h_segs.release(); seg_cached = 0;
+        wg_hist.release(); binned.release(); cursor.release(); h_out.release(); h_totals.release(); segs.release(); h_segs.release(); seg_cached = 0;
         done.release(); done_zeroed = 0;
     }
 };

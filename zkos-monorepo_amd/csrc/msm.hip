@@ -98,24 +98,46 @@ __global__ void msm_table_kernel(const G1Affine* bases, G1Affine* table, size_t 
 // (2^24 scalars x 16 windows = 268 M increments on 32768 counters: as global atomics that was 43 %
 // of the whole MSM.)  Each workgroup owns a contiguous range of scalars and keeps the bucket
 // histogram in LDS (NB + 1 words: 128 KB at c = 16, one workgroup per CU):
-//   msm_hist_kernel        LDS histogram of my range                 -> wg_hist[m][wg][b]
+//   msm_hist_kernel<0>     LDS histogram of my range                 -> wg_hist[m][wg][b]
 //   msm_hist_prefix_kernel per bucket: exclusive prefix over the workgroups (in place), total -> cnt
-//   msm_scan_kernel        bucket starts from the totals (as before)
-//   msm_scatter_kernel     LDS cursors start[b] + wg_hist[m][wg][b]; digits again, entries written
+//   msm_scan_kernel        bucket starts from the totals
+//   msm_hist_kernel<1>     LDS cursors start[b] + wg_hist[m][wg][b]; digits again, entries written
+//   (large inputs: msm_hist_kernel<2> + msm_bin_scatter_kernel instead of <1>, see below)
 // The order of the entries inside a bucket depends on the LDS atomics' arrival order; the bucket
 // SUM does not (exact group arithmetic), so results stay bit-identical.
 constexpr int DIG_THREADS = 1024;
 
-template <bool SCATTER>
+// Large MSMs scatter in TWO levels.  Written straight to its bucket, an entry is a 4-byte store to one of 2^15 cursors
+// per workgroup: a write frontier of megabytes per workgroup, so nearly every store reaches HBM as a partial line
+// (6.8 ms of a 30 ms MSM at 2^24).  Instead the entries are first grouped by BIN = 256 consecutive buckets
+// (msm_hist_kernel<2>: 128 cursors per workgroup, each filling whole lines; 8-byte entries that carry the bucket), then
+// msm_bin_scatter_kernel takes slices of that array, counts them per bucket in LDS, claims a range of each bucket's
+// region with one global atomic per (slice, bucket) and writes runs of ~32 entries.
+constexpr uint32_t BIN_LOG = 8;
+constexpr uint32_t SLICE = 8192;             // binned entries per workgroup of the second level (8 per thread)
+
+// MODE 0: count; 1: scatter straight to the buckets; 2: scatter to the bins
+template <int MODE>
 __global__ __launch_bounds__(DIG_THREADS) void msm_hist_kernel(const Fr* scalars, size_t n_scalars, size_t stride, size_t n_table,
                                                                uint32_t c, uint32_t W, uint32_t NB, uint32_t* wg_hist,
-                                                               const uint32_t* start, uint32_t* entries, size_t entries_stride) {
-    extern __shared__ uint32_t lds_cnt[];                       // NB + 1 words
+                                                               const uint32_t* start, uint32_t* entries, size_t entries_stride,
+                                                               uint64_t* binned) {
+    extern __shared__ uint32_t lds_cnt[];                       // NB + 1 words (MODE 2: one per bin)
     const uint32_t G = gridDim.x, wg = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
     uint32_t* row = wg_hist + ((size_t)m * G + wg) * (NB + 1);
-    if (SCATTER) {
+    if (MODE == 1) {
         const uint32_t* st = start + (size_t)m * (NB + 2);
         for (uint32_t b = tid; b <= NB; b += DIG_THREADS) lds_cnt[b] = st[b] + row[b];
+    } else if (MODE == 2) {
+        // cursor of bin k = start of its first bucket (256 k + 1) + what the workgroups before this one put into the bin
+        const uint32_t* st = start + (size_t)m * (NB + 2);
+        const uint32_t bins = NB >> BIN_LOG;
+        for (uint32_t k = tid; k < bins; k += DIG_THREADS) lds_cnt[k] = st[(k << BIN_LOG) + 1];
+        __syncthreads();
+        for (uint32_t b = tid; b < NB; b += DIG_THREADS) {
+            const uint32_t before = row[b + 1];
+            if (before) atomicAdd(&lds_cnt[b >> BIN_LOG], before);
+        }
     } else {
         for (uint32_t b = tid; b <= NB; b += DIG_THREADS) lds_cnt[b] = 0;
     }
@@ -136,13 +158,60 @@ __global__ __launch_bounds__(DIG_THREADS) void msm_hist_kernel(const Fr* scalars
                 carry = 1;
             }
             if (d == 0) continue;
-            const uint32_t pos = atomicAdd(&lds_cnt[d], 1u);
-            if (SCATTER) entries[(size_t)m * entries_stride + pos] = (uint32_t)((size_t)w * n_table + i) | (sign << 31);
+            const uint32_t ent = (uint32_t)((size_t)w * n_table + i) | (sign << 31);
+            if (MODE == 2) {
+                const uint32_t pos = atomicAdd(&lds_cnt[(d - 1) >> BIN_LOG], 1u);
+                binned[(size_t)m * entries_stride + pos] = (uint64_t)ent | ((uint64_t)d << 32);
+            } else {
+                const uint32_t pos = atomicAdd(&lds_cnt[d], 1u);
+                if (MODE == 1) entries[(size_t)m * entries_stride + pos] = ent;
+            }
         }
     }
-    if (!SCATTER) {
+    if (MODE == 0) {
         __syncthreads();
         for (uint32_t b = tid; b <= NB; b += DIG_THREADS) row[b] = lds_cnt[b];
+    }
+}
+
+// second level: slice blockIdx.x of the binned array (sorted by bin, so the buckets of a slice lie between those of its
+// first and its last entry's bins) -> the bucket regions of `entries`.  cursor[d] starts at start[d].
+__global__ __launch_bounds__(DIG_THREADS) void msm_bin_scatter_kernel(const uint64_t* binned, size_t entries_stride,
+                                                                      const uint32_t* start, uint32_t NB, uint32_t* cursor,
+                                                                      uint32_t* entries) {
+    extern __shared__ uint32_t lds_cnt[];                       // up to NB words: buckets [lo, hi) of this slice
+    const uint32_t m = blockIdx.y, tid = threadIdx.x;
+    const uint32_t total = start[(size_t)m * (NB + 2) + NB + 1];
+    const size_t s0 = (size_t)blockIdx.x * SLICE;
+    if (s0 >= total) return;
+    const uint32_t cnt = (uint32_t)(total - s0 < SLICE ? total - s0 : SLICE);
+    const uint64_t* src = binned + (size_t)m * entries_stride + s0;
+    uint32_t* cur = cursor + (size_t)m * (NB + 2);
+    uint32_t* dst = entries + (size_t)m * entries_stride;
+    const uint32_t d_first = (uint32_t)(src[0] >> 32), d_last = (uint32_t)(src[cnt - 1] >> 32);
+    const uint32_t lo = (((d_first - 1) >> BIN_LOG) << BIN_LOG) + 1;           // first bucket of the first bin
+    const uint32_t hi = ((((d_last - 1) >> BIN_LOG) + 1) << BIN_LOG) + 1;      // one past the last bucket of the last bin
+    for (uint32_t b = tid; b < hi - lo; b += DIG_THREADS) lds_cnt[b] = 0;
+    __syncthreads();
+    constexpr uint32_t PER = SLICE / DIG_THREADS;
+    uint64_t e[PER];
+    uint32_t rank[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t idx = k * DIG_THREADS + tid;
+        e[k] = idx < cnt ? src[idx] : 0;
+        if (idx < cnt) rank[k] = atomicAdd(&lds_cnt[(uint32_t)(e[k] >> 32) - lo], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < hi - lo; b += DIG_THREADS) {
+        const uint32_t c = lds_cnt[b];
+        if (c) lds_cnt[b] = atomicAdd(&cur[lo + b], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t idx = k * DIG_THREADS + tid;
+        if (idx < cnt) dst[lds_cnt[(uint32_t)(e[k] >> 32) - lo] + rank[k]] = (uint32_t)e[k];
     }
 }
 
@@ -233,6 +302,10 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const G1Aff
     acc.inf = true;
     bool first_run = true;
     pl->bucket = BUCKET_NONE;
+    // the gather of entry pos + 1 is in flight while entry pos is added: a random 64 B read from a table of many GB
+    // costs microseconds, and three waves per SIMD do not hide it behind a 2400-instruction addition on their own
+    uint32_t e_next = ent[begin];
+    G1Affine p_next = load_affine(table + (e_next & 0x7fffffffu));
     for (uint32_t pos = begin; pos < end; pos++) {
         if (pos >= boundary) {
             if (first_run) { pf->sum = to_g1x(acc); pf->bucket = cur; first_run = false; }
@@ -240,8 +313,12 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const G1Aff
             acc.inf = true;
             do { cur++; boundary = s[cur + 1]; } while (pos >= boundary);
         }
-        uint32_t e = ent[pos];
-        G1Affine p = table[e & 0x7fffffffu];
+        const uint32_t e = e_next;
+        const G1Affine p = p_next;
+        if (pos + 1 < end) {
+            e_next = ent[pos + 1];
+            p_next = load_affine(table + (e_next & 0x7fffffffu));
+        }
         if (p.is_inf()) continue;
         Fq y = (e >> 31) ? Fq::neg(p.y) : p.y;
         g1_madd29(acc, p.x, y);
@@ -1140,19 +1217,37 @@ void msm_run_ws(shp_msm* m, shp::MsmWorkspace& ws, const Fr* d_scalars, size_t n
     SHP_REQUIRE(lds_bytes <= 160 * 1024 - 512, SHP_ERR_INVALID_ARG, "msm: window too wide for the LDS histogram (c <= 16)");
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute((const void*)msm_hist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        (void)hipFuncSetAttribute((const void*)msm_hist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void*)msm_hist_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void*)msm_hist_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void*)msm_bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     });
     ws.wg_hist.reserve((size_t)batch * G * (NB + 1) * 4);
     uint32_t* wg_hist = ws.wg_hist.as<uint32_t>();
     SHP_HIP(hipMemsetAsync(cnt, 0, (size_t)batch * (NB + 2) * 4, st));
+    // two-level scatter for large inputs (whole bins of 256 buckets, and enough entries for a slice to bring a run to
+    // each bucket); SHP_MSM_TWO_LEVEL=0/1 forces the choice (tuning and tests)
+    const char* two_env = getenv("SHP_MSM_TWO_LEVEL");
+    const int force_two = two_env && *two_env ? atoi(two_env) : -1;
+    const bool two_level = (NB >> BIN_LOG) >= 2 && (force_two >= 0 ? force_two != 0 : entries_stride >= ((size_t)1 << 22));
     tm->begin(KID_MSM_DIGITS, st);
-    hipLaunchKernelGGL(msm_hist_kernel<false>, dim3(G, batch), dim3(DIG_THREADS), lds_bytes, st, d_scalars, n_scalars, stride,
-                       m->n, m->c, W, NB, wg_hist, (const uint32_t*)nullptr, (uint32_t*)nullptr, entries_stride);
+    hipLaunchKernelGGL(msm_hist_kernel<0>, dim3(G, batch), dim3(DIG_THREADS), lds_bytes, st, d_scalars, n_scalars, stride,
+                       m->n, m->c, W, NB, wg_hist, (const uint32_t*)nullptr, (uint32_t*)nullptr, entries_stride, (uint64_t*)nullptr);
     hipLaunchKernelGGL(msm_hist_prefix_kernel, dim3(ceil_div(NB + 1, 256), batch), dim3(256), 0, st, wg_hist, G, NB, cnt);
     hipLaunchKernelGGL(msm_scan_kernel, dim3(batch), dim3(MSM_THREADS), 0, st, cnt, start, NB);
-    hipLaunchKernelGGL(msm_hist_kernel<true>, dim3(G, batch), dim3(DIG_THREADS), lds_bytes, st, d_scalars, n_scalars, stride,
-                       m->n, m->c, W, NB, wg_hist, start, entries, entries_stride);
+    if (two_level) {
+        ws.binned.reserve((size_t)batch * entries_stride * 8);
+        ws.cursor.reserve((size_t)batch * (NB + 2) * 4);
+        SHP_HIP(hipMemcpyAsync(ws.cursor.p, start, (size_t)batch * (NB + 2) * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(msm_hist_kernel<2>, dim3(G, batch), dim3(DIG_THREADS), (size_t)(NB >> BIN_LOG) * 4, st, d_scalars,
+                           n_scalars, stride, m->n, m->c, W, NB, wg_hist, start, (uint32_t*)nullptr, entries_stride,
+                           ws.binned.as<uint64_t>());
+        hipLaunchKernelGGL(msm_bin_scatter_kernel, dim3(ceil_div(entries_stride, SLICE), batch), dim3(DIG_THREADS),
+                           (size_t)NB * 4, st, ws.binned.as<uint64_t>(), entries_stride, start, NB, ws.cursor.as<uint32_t>(),
+                           entries);
+    } else {
+        hipLaunchKernelGGL(msm_hist_kernel<1>, dim3(G, batch), dim3(DIG_THREADS), lds_bytes, st, d_scalars, n_scalars, stride,
+                           m->n, m->c, W, NB, wg_hist, start, entries, entries_stride, (uint64_t*)nullptr);
+    }
     tm->end(st);
     SHP_HIP(hipMemsetAsync(buckets, 0, (size_t)batch * (NB + 1) * sizeof(G1X), st));
     tm->begin(KID_MSM_ACCUMULATE, st);
