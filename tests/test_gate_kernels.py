@@ -1,0 +1,70 @@
+"""The gate kernels compiled ahead of time for the shipped circuit plans (tools/gen_gate_kernels.py ->
+zkos-monorepo_amd/csrc/gate_kernels.inc): the committed file is what the plans generate, a key over a shipped plan uses
+its compiled kernel, and compiled and interpreted gate programs give the same proof bytes -- the oracle's."""
+import importlib
+import os
+import random
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAU = 0x1234567890ABCDEF1234567890ABCDEF55
+
+
+def test_committed_gate_kernels_are_what_the_plans_generate():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_gate_kernels.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_compiled_and_interpreted_gate_programs_give_the_oracle_proof(shp, oracle, gpu_ctx, monkeypatch):
+    PL = importlib.import_module("oracle.plonk")
+    C = importlib.import_module("zkos-monorepo_amd.circuits")
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    for build, wit_of in ((lambda: C.build_withdraw_plan(k=9, height=1, range_bits=4, range_chunks=8),
+                           lambda lay: C.withdraw_witness_inputs(lay, H, random.Random(3), 2**31 + 5, 2**20 + 3)),):
+        plan_bytes, lay = build()
+        plan = PL.Plan(plan_bytes)
+        osrs = oracle.srs_synthetic(plan.k, TAU)
+        opk = PL.keygen(plan, osrs)
+        params = shp.Params.synthetic(gpu_ctx, plan.k, TAU)
+        wit = wit_of(lay)
+        seed = bytes([7]) * 32
+        want = PL.prove(opk, osrs, wit, seed)
+        monkeypatch.delenv("SHP_GATE_AOT", raising=False)
+        pk_c = shp.ProvingKey(gpu_ctx, params, plan_bytes)
+        assert pk_c.gate_compiled(), "the withdraw-shaped plan is shipped with a compiled gate kernel"
+        monkeypatch.setenv("SHP_GATE_AOT", "0")
+        pk_i = shp.ProvingKey(gpu_ctx, params, plan_bytes)
+        assert not pk_i.gate_compiled()
+        monkeypatch.delenv("SHP_GATE_AOT", raising=False)
+        for pk in (pk_c, pk_i):
+            for mode in (False, True):                     # latency and throughput lanes pick different interpreters
+                pr = shp.Prover(pk)
+                pr.mode(mode)
+                assert pr.prove(wit, seed) == want
+                pr.close()
+        pk_c.close(); pk_i.close(); params.close()
+
+
+@pytest.mark.gpu
+def test_a_plan_the_library_does_not_ship_is_interpreted(shp, oracle, gpu_ctx):
+    B = importlib.import_module("zkos-monorepo_amd.circuits.builder")
+    b = B.PlanBuilder(6)
+    a0 = b.advice_column()
+    tab = b.fixed_column()
+    for r in range(16):
+        b.fix(tab, r, r)
+    b.lookup([B.Adv(a0, 0)], [B.Fix(tab, 0)])
+    b.enable_equality(B.COL_ADVICE, a0)
+    b.n_winputs = 2
+    b.w(B.W_INPUT, (a0, 0), imm=0)
+    b.w(B.W_INPUT, (a0, 1), imm=1)
+    b.copy((B.COL_ADVICE, a0, 0), (B.COL_ADVICE, a0, 1))
+    tsrs = oracle.srs_synthetic(6, TAU)
+    params = shp.Params.from_parts(gpu_ctx, 6, tsrs.g, tsrs.g_lagrange)
+    pk = shp.ProvingKey(gpu_ctx, params, b.build())
+    assert not pk.gate_compiled()
+    pk.close(); params.close()

@@ -423,6 +423,12 @@ class ProvingKey:
                                       C.byref(ok), words, C.c_size_t(22 * 32)))
         return bool(ok.value), [int.from_bytes(words.raw[32 * i:32 * i + 32], "big") for i in range(22)]
 
+    def gate_compiled(self) -> bool:
+        """True when the key's gate expressions run as a kernel compiled ahead of time (a plan the library ships)"""
+        v = C.c_int32(0)
+        _check(lib().shp_pk_gate_compiled(self.h, C.byref(v)))
+        return bool(v.value)
+
     def vk_digest(self) -> bytes:
         out = C.create_string_buffer(32)
         _check(lib().shp_pk_vk_digest(self.h, out))

@@ -90,6 +90,7 @@ struct shp_pk {
     Fr *l0 = nullptr, *l_last = nullptr, *l_active = nullptr;
     Fr *x_ext = nullptr, *omegas = nullptr, *t_inv = nullptr, *consts = nullptr;
     Instr* gate_prog = nullptr;
+    void (*gate_fn)(ProgArgs) = nullptr;           // the compiled gate program, when the plan is one the library ships
     std::vector<Instr*> lk_in_prog, lk_tab_prog;
     Query *adv_q = nullptr, *fix_q = nullptr, *inst_q = nullptr;
     // host copies
@@ -120,6 +121,42 @@ struct shp_pk {
         for (void* p : owned) (void)hipFree(p);
     }
 };
+
+// Gate programs compiled ahead of time (tools/gen_gate_kernels.py): the circuits are fixed when the library is built, as
+// they are for the reference (/root/reference/crates/shielder_bindings/build.rs:19-48), so the plans the library ships
+// get their gate expressions as straight-line code -- no operand moves through the slot file, no dispatch: 36.6 k
+// vector instructions per 64 rows of the withdraw program instead of the interpreter's 53 k.  Any other plan is
+// interpreted; both give the same values.
+#include "gate_kernels.inc"
+
+typedef void (*GateKernelFn)(ProgArgs);
+
+// FNV-1a over what the generated code depends on: slot count, instructions, the three query lists
+static uint64_t gate_program_hash(const PlanData& P) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    auto eat = [&](uint32_t w) {
+        for (int i = 0; i < 4; i++) {
+            h = (h ^ ((w >> (8 * i)) & 0xffu)) * 0x100000001B3ull;
+        }
+    };
+    eat(P.gate_slots);
+    eat((uint32_t)P.gate_prog.size());
+    for (const Instr& in : P.gate_prog) { eat(in.op); eat(in.dst); eat(in.a); eat(in.b); }
+    for (const std::vector<Query>* qs : {&P.adv_q, &P.fix_q, &P.inst_q}) {
+        eat((uint32_t)qs->size());
+        for (const Query& q : *qs) { eat(q.col); eat((uint32_t)q.rot); }
+    }
+    return h;
+}
+
+static GateKernelFn find_gate_kernel(const PlanData& P) {
+    const char* e = getenv("SHP_GATE_AOT");
+    if (e && e[0] == '0') return nullptr;                    // A/B and tests: always interpret
+    const uint64_t h = gate_program_hash(P);
+    for (const GateKernelEntry& g : GATE_KERNELS)
+        if (g.hash == h && g.n_instr == P.gate_prog.size()) return g.fn;
+    return nullptr;
+}
 
 static void launch_prog(hipStream_t st, const ProgArgs& a, uint32_t size, bool throughput) {
     // up to 16 slots: the register-file interpreter (no LDS) for throughput lanes -- it leaves the CU's LDS to the
@@ -280,6 +317,7 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     }
     pk->consts = pk->dupload(P.consts);
     pk->gate_prog = pk->dupload(P.gate_prog);
+    pk->gate_fn = find_gate_kernel(P);
     for (auto& lk : P.lookups) {
         pk->lk_in_prog.push_back(pk->dupload(lk.in_prog));
         pk->lk_tab_prog.push_back(pk->dupload(lk.tab_prog));
@@ -1099,7 +1137,8 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     pa.prog = pk->gate_prog; pa.n_instr = (uint32_t)P.gate_prog.size(); pa.nslots = P.gate_slots;
     pa.out = pr->h;
     pr->timers.begin(KID_PROG, st);
-    launch_prog(st, pa, ne, pr->throughput);
+    if (pk->gate_fn) hipLaunchKernelGGL(pk->gate_fn, dim3(ne / PROG_THREADS), dim3(PROG_THREADS), 0, st, pa);
+    else launch_prog(st, pa, ne, pr->throughput);
     pr->timers.end(st);
     if (S) {
         PermQArgs q;
@@ -1507,6 +1546,13 @@ int32_t shp_pk_info(const shp_pk* pk, uint32_t* k, uint32_t* n_witness_inputs, u
         if (n_witness_inputs) *n_witness_inputs = P.n_winputs;
         if (n_instances) *n_instances = P.num_instance;
         if (proof_len) *proof_len = 64 * n_points + 32 * n_evals + 128;
+    });
+}
+
+int32_t shp_pk_gate_compiled(const shp_pk* pk, int32_t* compiled) {
+    return guarded([&] {
+        SHP_REQUIRE(pk && compiled, SHP_ERR_INVALID_ARG, "pk_gate_compiled: null argument");
+        *compiled = pk->gate_fn ? 1 : 0;
     });
 }
 
