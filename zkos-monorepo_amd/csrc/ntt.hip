@@ -14,8 +14,9 @@
 //     global access is a run of 2^c * 32 B >= 128 B.
 //   * Inside the tile: s decimation-in-frequency stages, twiddles from a 32 KiB table of
 //     w_2048^j that stays in L2; the bit reversal is folded into the read-out index.
-//   * Between passes: the element is scaled by w_N^(k_p * lo) = hi[e >> h] * lo[e & mask]
-//     (two small L2-resident tables instead of an N-entry table that would double the traffic).
+//   * Between passes: the element is scaled by w_N^(k_p * lo), read from a table of all N powers for domains up to
+//     2^24 (the extra 32 B per element is HBM traffic the transform has room for; a second product is not), and as
+//     hi[e >> h] * lo[e & mask] from two small tables above that.
 //   * The last pass writes in digit-reversed = natural order, 2^c adjacent outputs per run,
 //     so there is no separate bit-reversal sweep.  1/n, and the zeta-coset scalings of
 //     coeff_to_extended / extended_to_coeff, are fused into the first load / last store.
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
             go = ((size_t)hi << (s + p.lo_bits)) | ((size_t)kp << p.lo_bits) | lo;
             uint64_t et = (((uint64_t)kp * lo) << hi_bits) << p.tw_shift;
             if (et) {
-                // domains up to 2^18 keep every power in one (L2-resident) table: one product instead of two
+                // domains up to 2^24 keep every power in one table: one product instead of two
                 Fr tw = gload(p.tw_lo + (et & ((1u << p.h) - 1)));
                 if (p.h < p.log_n + p.tw_shift) tw = gload(p.tw_hi + (et >> p.h)) * tw;
                 val = val * tw;
@@ -227,6 +228,36 @@ static Fr* upload_powers(const Fr& base, size_t count) {
     return d;
 }
 
+// out[i] = base^i for i < count, on the device: thread t raises base to t * 64 by square-and-multiply and walks 64
+// entries from there (the tables of the large domains have up to 2^24 entries; the host loop above takes a second there)
+__global__ void ntt_powers_kernel(Fr base, size_t count, Fr* out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i0 = t * 64;
+    if (i0 >= count) return;
+    Fr acc = Fr::one(), sq = base;
+    for (size_t e = i0; e; e >>= 1) {
+        if (e & 1) acc = acc * sq;
+        sq = Fr::sqr(sq);
+    }
+    const size_t i1 = i0 + 64 < count ? i0 + 64 : count;
+    for (size_t i = i0; i < i1; i++) {
+        gstore(out + i, acc);
+        acc = acc * base;
+    }
+}
+
+static Fr* device_powers(shp_ctx* ctx, const Fr& base, size_t count) {
+    if (count <= 4096) return upload_powers(base, count);
+    Fr* d = nullptr;
+    SHP_HIP(hipMalloc(&d, count * sizeof(Fr)));
+    const size_t threads = (count + 63) / 64;
+    hipLaunchKernelGGL(ntt_powers_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, ctx->stream, base, count, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d); SHP_HIP(e); }
+    return d;
+}
+
 // tables shared by every size (caller holds ctx->mu)
 static void ntt_small_tables(shp_ctx* ctx) {
     if (ctx->ntt_small[0]) return;
@@ -244,11 +275,15 @@ const NttTables& ntt_tables_for(shp_ctx* ctx, uint32_t log_n) {
     if (it != ctx->ntt_tables.end()) return it->second;
     NttTables t;
     t.log_n = log_n;
-    t.h = log_n <= 18 ? log_n : (log_n + 1) / 2;
+    // Every power in ONE table up to 2^24 points (512 MB per direction at 2^24: HBM has the room and the bandwidth --
+    // the transform uses 5 % of it -- while a second product per element per pass boundary for hi * lo is ALU time);
+    // above that the exponent is split into two table lookups and a product.  SHP_NTT_FULL_TABLE_LOG overrides the limit.
+    static const uint32_t full_log = getenv("SHP_NTT_FULL_TABLE_LOG") ? (uint32_t)atoi(getenv("SHP_NTT_FULL_TABLE_LOG")) : 24;
+    t.h = log_n <= full_log ? log_n : (log_n + 1) / 2;
     Fr w = fr_root_of_unity(log_n);
     Fr wi = Fr::inv(w);
-    t.lo[0] = upload_powers(w, (size_t)1 << t.h);
-    t.lo[1] = upload_powers(wi, (size_t)1 << t.h);
+    t.lo[0] = device_powers(ctx, w, (size_t)1 << t.h);
+    t.lo[1] = device_powers(ctx, wi, (size_t)1 << t.h);
     t.hi[0] = upload_powers(pow2k(w, t.h), (size_t)1 << (log_n - t.h));
     t.hi[1] = upload_powers(pow2k(wi, t.h), (size_t)1 << (log_n - t.h));
     t.n_inv = Fr::inv(Fr::from_u64(1ull << log_n));
