@@ -36,8 +36,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # Proving lanes are HIP streams, and ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues: kernels of lanes that share a
-# queue run one after the other.  The 16 lanes need 16 queues (measured on one box: 1149 proofs/s at 4 queues, 1400 at 16,
-# 1356 at 32).  The value must be in the environment before the HIP runtime initialises; a host that exports a smaller one
+# queue run one after the other.  The lanes need 16 queues (measured on one box: 1149 proofs/s at 4 queues, 1400 at 16,
+# 1356 at 32; with 48 lanes 1764 at 16 and 1525 at 24).  The value must be in the environment before the HIP runtime initialises; a host that exports a smaller one
 # (HIP's own default is 4) is raised to 16 here, SHP_BENCH_HW_QUEUES overrides.
 HW_QUEUES = int(os.environ.get("SHP_BENCH_HW_QUEUES", "16"))
 if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < HW_QUEUES or "SHP_BENCH_HW_QUEUES" in os.environ:
@@ -129,7 +129,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--lanes", type=int, default=32, help="concurrent proving lanes (streams) per GPU")
+    ap.add_argument("--lanes", type=int, default=48, help="concurrent proving lanes (streams) per GPU "
+                    "(measured on one MI355X: 1694 / 1721 / 1764 / 1768 proofs/s at 24 / 32 / 48 / 64)")
     ap.add_argument("--proofs-per-lane", type=int, default=4, help="proofs each lane produces back to back in one step")
     ap.add_argument("--latency-proofs", type=int, default=100, help="single-lane proofs timed for p50 (the metric's latency half: 100 runs)")
     ap.add_argument("--cpu-proofs", type=int, default=3, help="size of the CPU-baseline sample (0 = skip)")
