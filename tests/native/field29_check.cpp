@@ -86,6 +86,31 @@ int main(int argc, char** argv) {
             if (!same_point(to_g1x(acc), ref)) { printf("madd29 mismatch: chain %d step %d kind %d\n", it, s, (int)kind); return 1; }
         }
     }
-    printf("ok %d products, %ld additions\n", rounds, adds);
+    // 3. general additions: random pairs of partial sums, equal points (doubling), opposite points, the identity
+    long gadds = 0;
+    for (int it = 0; it < rounds / 4 + 1; it++) {
+        G1X ra = G1X::inf(), rb = G1X::inf();
+        G1X29 a29, b29;
+        a29.inf = true; b29.inf = true;
+        const int la = (int)(rnd() % 6), lb = (int)(rnd() % 6);       // 0 additions: the identity
+        for (int s = 0; s < la; s++) { const G1Affine q = pts[rnd() % n_pts]; ra = g1_madd(ra, q.x, q.y); g1_madd29(a29, q.x, q.y); }
+        for (int s = 0; s < lb; s++) { const G1Affine q = pts[rnd() % n_pts]; rb = g1_madd(rb, q.x, q.y); g1_madd29(b29, q.x, q.y); }
+        const uint64_t kind = rnd() % 8;
+        if (kind == 0) { rb = ra; b29 = a29; }                         // doubling (or identity + identity)
+        if (kind == 1) { rb = ra.negated(); b29 = from_g1x(rb); }      // cancels
+        if (kind == 2 && !ra.is_inf()) {                               // the same point under another representation
+            const G1Affine q = g1_to_affine(ra);
+            rb = G1X::from_affine(q); b29 = from_g1x(rb);
+        }
+        G1X want = g1_add(ra, rb);
+        G1X29 got = g1_add29(a29, b29);
+        gadds++;
+        if (!same_point(to_g1x(got), want)) { printf("add29 mismatch: case %d kind %d\n", it, (int)kind); return 1; }
+        // sums of sums keep the bounds: feed the result back in
+        G1X want2 = g1_add(want, ra);
+        G1X29 got2 = g1_add29(got, a29);
+        if (!same_point(to_g1x(got2), want2)) { printf("add29 (second level) mismatch: case %d kind %d\n", it, (int)kind); return 1; }
+    }
+    printf("ok %d products, %ld additions, %ld general additions\n", rounds, adds, gadds);
     return 0;
 }

@@ -224,7 +224,7 @@ SHP_HD Fq29 from_fq_reduced(const Fq& x) {
 // XYZZ accumulator in the lazy form.  Bounds between additions: x < 10.5 p, y < 5.5 p, zz, zzz < 2.5 p.
 struct G1X29 {
     Fq29 x, y, zz, zzz;
-    bool inf;
+    uint32_t inf;            // a full word: a bool leaves three padding bytes, and copying those goes through scratch memory
 };
 
 SHP_HD G1X to_g1x(const G1X29& a) {
@@ -283,5 +283,33 @@ SHP_HD void g1_madd29(G1X29& acc, const Fq& qx, const Fq& qy) {
     acc.zzz = mul29(acc.zzz, PPP);
 }
 
+// acc + q, both in the lazy form with the accumulator bounds above (add-2008-s, 12 products + 2 squarings); the result
+// keeps those bounds.  P = u2 - u1 + 3 p < 5.5 p is a multiple of p exactly when the points share their x: those lanes
+// (and the one in 2^29 / 6 whose low limb says so by chance) take the exact 8 x 32 path.
+SHP_HD G1X29 g1_add29(const G1X29& a, const G1X29& b) {
+    if (a.inf) return b;
+    if (b.inf) return a;
+    const Fq29 u1 = mul29(a.x, b.zz), u2 = mul29(b.x, a.zz);
+    const Fq29 s1 = mul29(a.y, b.zzz), s2 = mul29(b.y, a.zzz);
+    const Fq29 P = sub29(u2, u1, f29::KP3);                               // < 5.5 p
+    if (((P.l[0] * f29::PPOSINV29) & M29) < 6u) return from_g1x(g1_add(to_g1x(a), to_g1x(b)));
+    const Fq29 Rr = sub29(s2, s1, f29::KP3);                              // < 5.5 p
+    const Fq29 PP = sqr29(P);
+    const Fq29 PPP = mul29(P, PP);
+    const Fq29 Q = mul29(u1, PP);
+    const Fq29 R2 = sqr29(Rr);
+    G1X29 r;
+    r.inf = false;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.x.l[i] = R2.l[i] + f29::KP8W.l[i] - PPP.l[i] - (Q.l[i] << 1);
+    normalise29(r.x);                                                      // < 10.5 p
+    Fq29 T;
+#pragma unroll
+    for (int i = 0; i < 9; i++) T.l[i] = Q.l[i] + f29::KP11.l[i] - r.x.l[i];  // < 13.5 p, one lazy operand
+    r.y = sub29(mul29(Rr, T), mul29(s1, PPP), f29::KP3);                  // < 5.5 p
+    r.zz = mul29(mul29(a.zz, b.zz), PP);
+    r.zzz = mul29(mul29(a.zzz, b.zzz), PPP);
+    return r;
+}
 
 }  // namespace shp

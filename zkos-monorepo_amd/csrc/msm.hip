@@ -728,11 +728,154 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
     return r;
 }
 
+// The same sum over accumulators in the 29-bit lazy form (field29.cuh): 226 instructions per product instead of ~330,
+// and the 256 accumulators of a workgroup are not converted back to the 8 x 32-bit form first (four products each) --
+// only the one sum is.  Same rounds, same lanes; every value keeps the accumulator bounds of g1_add29.  Slots carry an
+// identity flag of their own (a lazy zz has no canonical zero).
+constexpr uint32_t C29_POINT_WORDS = 36 * COOP_SLOTS;         // [4 coords][9 limbs][128 slots]
+constexpr uint32_t C29_SCR_WORDS = 9 * 9 * 64;                // [9 values][9 limbs][64 quads]
+constexpr uint32_t C29_LDS_WORDS = C29_POINT_WORDS + C29_SCR_WORDS + 64 + COOP_SLOTS;
+
+__device__ __forceinline__ G1X29 block_sum_256_29(G1X29 acc, uint32_t* sh /* [C29_LDS_WORDS] */) {
+    const uint32_t t = threadIdx.x;
+    uint32_t* scr = sh + C29_POINT_WORDS;
+    uint32_t* flg = scr + C29_SCR_WORDS;                        // per quad: bit0 inf1, bit1 inf2, bit2 same x (maybe)
+    uint32_t* infl = flg + 64;                                  // per slot: the point is the identity
+    auto ldc = [&](uint32_t coord, uint32_t slot) {
+        Fq29 v;
+#pragma unroll
+        for (int i = 0; i < 9; i++) v.l[i] = sh[(coord * 9 + i) * COOP_SLOTS + slot];
+        return v;
+    };
+    auto stc = [&](uint32_t coord, uint32_t slot, const Fq29& v) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) sh[(coord * 9 + i) * COOP_SLOTS + slot] = v.l[i];
+    };
+    auto lds = [&](uint32_t val, uint32_t quad) {
+        Fq29 v;
+#pragma unroll
+        for (int i = 0; i < 9; i++) v.l[i] = scr[(val * 9 + i) * 64 + quad];
+        return v;
+    };
+    auto sts = [&](uint32_t val, uint32_t quad, const Fq29& v) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) scr[(val * 9 + i) * 64 + quad] = v.l[i];
+    };
+    auto put = [&](uint32_t slot, const G1X29& p) {
+        stc(0, slot, p.x); stc(1, slot, p.y); stc(2, slot, p.zz); stc(3, slot, p.zzz);
+        infl[slot] = p.inf ? 1u : 0u;
+    };
+    auto get = [&](uint32_t slot) {
+        G1X29 p;
+        p.x = ldc(0, slot); p.y = ldc(1, slot); p.zz = ldc(2, slot); p.zzz = ldc(3, slot);
+        p.inf = infl[slot] != 0;
+        return p;
+    };
+    if (t >= 128) put(t - 128, acc);
+    __syncthreads();
+    if (t < 128) {
+        acc = g1_add29(acc, get(t));
+        put(t, acc);
+    }
+    __syncthreads();
+    enum { V_U1 = 0, V_S1, V_U2, V_S2, V_PPU, V_PP, V_RR, V_RR2, V_PPP };
+    const uint32_t q = t >> 2, j = t & 3;
+    const Fq29 zero29 = {};
+    for (uint32_t m = 64; m >= 1; m >>= 1) {
+        const bool act = t < 4 * m;
+        const bool wave_act = (t & ~63u) < 4 * m;               // a wave with no lane in the level skips the products
+        const uint32_t a = q, b = q + m;
+        Fq29 mine = zero29, keep = zero29;
+        // R1: u1 = x1 zz2 | s1 = y1 zzz2 | u2 = x2 zz1 | s2 = y2 zzz1
+        Fq29 A1 = zero29, B1 = zero29;
+        if (act) {
+            A1 = ldc(j & 1, (j & 2) ? b : a);
+            B1 = ldc(2 + (j & 1), (j & 2) ? a : b);
+        }
+        if (wave_act) mine = mul29(A1, B1);
+        if (act) sts(V_U1 + j, q, mine);
+        __syncthreads();
+        // R2: pp = (u2 - u1)^2 | rr2 = (s2 - s1)^2 | zz12 | zzz12
+        Fq29 A2 = zero29, B2 = zero29;
+        if (act) {
+            if (j < 2) {
+                A2 = sub29(lds(V_U2 + j, q), mine, f29::KP3);    // < 5.5 p
+                B2 = A2;
+                sts(j == 0 ? V_PPU : V_RR, q, A2);
+                if (j == 0)
+                    flg[q] = (infl[a] ? 1u : 0u) | (infl[b] ? 2u : 0u) | ((((A2.l[0] * f29::PPOSINV29) & M29) < 6u) ? 4u : 0u);
+            } else {
+                A2 = ldc(j, a);
+                B2 = ldc(j, b);
+            }
+        }
+        if (wave_act) keep = mul29(A2, B2);
+        if (act && j < 2) sts(j == 0 ? V_PP : V_RR2, q, keep);
+        __syncthreads();
+        // R3: qq = u1 pp | - | zz3 = zz12 pp | ppp = (u2 - u1) pp
+        Fq29 A3 = zero29, B3 = zero29;
+        if (act) {
+            B3 = lds(V_PP, q);
+            A3 = j == 0 ? mine : keep;
+            if (j == 3) A3 = lds(V_PPU, q);
+        }
+        Fq29 r3 = zero29;
+        if (wave_act) r3 = mul29(A3, B3);
+        if (act && j == 3) sts(V_PPP, q, r3);
+        __syncthreads();
+        // R4: x3 = rr2 - ppp - 2 qq, t2 = rr (qq - x3) | t1 = s1 ppp | - | zzz3 = zzz12 ppp
+        Fq29 A4 = zero29, B4 = zero29, out = r3;                  // lane 2: zz3
+        if (act) {
+            if (j == 0) {
+                const Fq29 rr2 = lds(V_RR2, q), ppp = lds(V_PPP, q);
+#pragma unroll
+                for (int i = 0; i < 9; i++) out.l[i] = rr2.l[i] + f29::KP8W.l[i] - ppp.l[i] - (r3.l[i] << 1);
+                normalise29(out);                                 // x3 < 10.5 p
+                A4 = lds(V_RR, q);
+#pragma unroll
+                for (int i = 0; i < 9; i++) B4.l[i] = r3.l[i] + f29::KP11.l[i] - out.l[i];   // qq - x3 + 11 p, one lazy operand
+            } else if (j == 1) {
+                A4 = mine;                                        // s1
+                B4 = lds(V_PPP, q);
+            } else if (j == 3) {
+                A4 = keep;                                        // zzz12
+                B4 = r3;                                          // ppp
+            }
+        }
+        Fq29 r4 = zero29;
+        if (wave_act) r4 = mul29(A4, B4);                         // t2 | t1 | - | zzz3
+        if (act && j == 0) sts(V_U2, q, r4);
+        if (j == 3) out = r4;
+        __syncthreads();
+        // R5: y3, select around identities, write the sum into slot a
+        bool special = false;
+        if (act) {
+            const uint32_t f = flg[q];
+            if (j == 1) out = sub29(lds(V_U2, q), r4, f29::KP3);  // y3 = t2 - t1 < 5.5 p
+            if (f & 1u) {                                         // P = O: the sum is Q
+                stc(j, a, ldc(j, b));
+                if (j == 0) infl[a] = (f >> 1) & 1u;
+            } else if (f & 2u) {                                  // Q = O: the sum is P, already in slot a
+            } else if (f & 4u) special = true;                    // same x (or a chance hit): exact arithmetic
+            else stc(j, a, out);
+        }
+        if (__syncthreads_or(special ? 1 : 0)) {
+            if (act && j == 0 && special) put(a, g1_add29(get(a), get(b)));
+            __syncthreads();
+        }
+    }
+    G1X29 r;
+    r.inf = true;
+    if (t == 0) r = get(0);
+    return r;
+}
+
 // lane <-> scalar i, blockIdx.y <-> group of T windows, blockIdx.x <-> (segment, MSM of its batch, 256-row block):
 // only row blocks a segment visits are launched (an empty workgroup still costs ~0.1 us of dispatch)
 template <bool LAZY29>
 __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a) {
-    __shared__ uint32_t sh[COOP_LDS_WORDS];
+    __shared__ uint32_t sh[LAZY29 ? C29_LDS_WORDS : COOP_LDS_WORDS];
+    static_assert(C29_LDS_WORDS >= COOP_LDS_WORDS, "the final merge of the partial sums uses the 8 x 32-bit tree");
     uint32_t lo = 0, hi = a.n_segs;                            // last segment with wg_base <= blockIdx.x
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -795,8 +938,12 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
             }
         }
     }
-    if constexpr (LAZY29) acc = to_g1x(acc29);
-    acc = block_sum_256(acc, sh);
+    if constexpr (LAZY29) {
+        const G1X29 sum29 = block_sum_256_29(acc29, sh);
+        if (threadIdx.x == 0) acc = to_g1x(sum29);
+    } else {
+        acc = block_sum_256(acc, sh);
+    }
     // The workgroup that stores the last partial sum of an MSM adds them all up: no second dispatch (on a busy chip a
     // dispatch costs its stream tens of microseconds whatever its size).  Device-scope fences on both sides of the
     // count make the partials of workgroups on other XCDs (other L2s) visible to the one that reads them.
