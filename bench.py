@@ -36,10 +36,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # Proving lanes are HIP streams, and ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues: kernels of lanes that share a
-# queue run one after the other.  The lanes need 16 queues (measured on one box: 1149 proofs/s at 4 queues, 1400 at 16,
-# 1356 at 32; with 48 lanes 1764 at 16 and 1525 at 24).  The value must be in the environment before the HIP runtime initialises; a host that exports a smaller one
-# (HIP's own default is 4) is raised to 16 here, SHP_BENCH_HW_QUEUES overrides.
-HW_QUEUES = int(os.environ.get("SHP_BENCH_HW_QUEUES", "16"))
+# queue run one after the other.  Measured with 48 lanes on one MI355X: 1710 proofs/s on 12 queues, 1804 on 16, 1828 on 18,
+# 1859 on 20, 1887 on 22 -- and 1544 on 24 or 28: past 22 the runtime runs out of hardware queues of its own and multiplexes.
+# The value must be in the environment before the HIP runtime initialises; a host that exports a smaller one (HIP's own
+# default is 4) is raised here, SHP_BENCH_HW_QUEUES overrides.
+HW_QUEUES = int(os.environ.get("SHP_BENCH_HW_QUEUES", "22"))
 if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < HW_QUEUES or "SHP_BENCH_HW_QUEUES" in os.environ:
     os.environ["GPU_MAX_HW_QUEUES"] = str(min(HW_QUEUES, 32))
 os.environ["SHP_KEEP_HW_QUEUES"] = "1"                  # the package would raise a smaller value to 16 again
