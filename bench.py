@@ -297,7 +297,9 @@ def main():
     # dominant kernel family of the timed region, by summed HIP-event time
     dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (0, 0.0))
     name, (cnt, ms) = dom
-    launches_per_proof = cnt / max(1, a.steps * per_step)
+    # the HIP-event clock runs on --event-lanes of the lanes only: those lanes proved their share of the proofs
+    timed_proofs = max(1.0, a.steps * per_step * min(a.event_lanes, a.lanes) / float(a.lanes))
+    launches_per_proof = cnt / timed_proofs
     # algorithmic bytes of one MSM launch: 96 B per point: 32 B scalar + 64 B base.  The prover issues 25 MSMs of n
     # points per proof in 6 batched launches: the average launch moves 25/6 scalar vectors + one base table.
     msm_launch_bytes = (25.0 / 6.0) * 32 * n + 64 * n
@@ -379,7 +381,7 @@ def main():
                      "traffic": traffic,
                      "fr_mul_ceiling_per_s": ctx.fr_mul_rate(2048),
                      "kernel_source_id": src_id},
-        "kernel_ms_per_proof": {k_: v[1] / max(1, a.steps * per_step) for k_, v in sorted(prof.items()) if v[0]},
+        "kernel_ms_per_proof": {k_: v[1] / timed_proofs for k_, v in sorted(prof.items()) if v[0]},
         "kernel_us_per_launch_alone": {k_: 1e3 * ms_ / c_ for k_, (c_, ms_) in sorted(alone.items())},
     }
     pool.close()
