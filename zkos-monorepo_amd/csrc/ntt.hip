@@ -126,7 +126,9 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
     }
     __syncthreads();
 
-    // ---- s decimation-in-frequency stages in LDS
+    // ---- s decimation-in-frequency stages in LDS, one per sweep.  (Two stages per sweep on a quad of elements in
+    // registers -- half the LDS round trips and barriers -- was measured and lost: 134 VGPRs allow one tile per CU
+    // instead of two, 2^24 in 2.88 ms instead of 2.5; capped at 128 VGPRs the quad spills to scratch.)
     for (int t = (int)s - 1; t >= 0; t--) {
         const uint32_t half = 1u << t;
         for (uint32_t b = tid; b < (E >> 1); b += THREADS) {
@@ -360,6 +362,7 @@ static void ntt_launch_with(shp_ctx* ctx, const NttTables& T, uint32_t tw_shift,
         uint32_t tiles = (uint32_t)(N >> (p.s + p.c));
         static const int forced = getenv("SHP_NTT_THREADS") ? atoi(getenv("SHP_NTT_THREADS")) : 0;   // tuning aid
         int threads = (uint64_t)tiles * batch <= (uint64_t)4 * ctx->num_cus ? 1024 : 512;   // measured: 2^24 3.07 ms (256) / 2.82 (512) / 3.02 (1024)
+        if (o.throughput) threads = 512;
         if (forced == 256 || forced == 512 || forced == 1024) threads = forced;
         if (threads == 1024)
             hipLaunchKernelGGL(ntt_pass_kernel<1024>, dim3(tiles, batch), dim3(1024), 0, st, p);
