@@ -66,7 +66,7 @@ def kernel_source_id():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "zkos-monorepo_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".cuh", ".hpp", ".inc")):
+        if f.endswith((".hip", ".hpp", ".inc")):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

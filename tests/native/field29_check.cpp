@@ -2,7 +2,7 @@
 // Exit code 0 and a line "ok ..." when every comparison holds; the first mismatch is printed and the exit code is 1.
 #include <stdio.h>
 #include <stdlib.h>
-#include "../../zkos-monorepo_amd/csrc/field29.cuh"
+#include "../../zkos-monorepo_amd/csrc/field29.hip.hpp"
 
 using namespace shp;
 

@@ -1,4 +1,4 @@
-"""The 29-bit-limb Fq of the MSM kernels (zkos-monorepo_amd/csrc/field29.cuh) against the 8 x 32-bit arithmetic, on the CPU:
+"""The 29-bit-limb Fq of the MSM kernels (zkos-monorepo_amd/csrc/field29.hip.hpp) against the 8 x 32-bit arithmetic, on the CPU:
 both compile for the host, so products, squares, lazy subtractions and chains of mixed additions (with doublings, opposite
 points and the identity spliced in) are compared value for value without a GPU."""
 import os

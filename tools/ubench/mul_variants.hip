@@ -18,7 +18,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "field.cuh"
+#include "field.hip.hpp"
 
 using shp::Fq;
 

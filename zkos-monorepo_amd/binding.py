@@ -31,7 +31,7 @@ class ShpError(RuntimeError):
 def build(force=False):
     """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(_DIR, "csrc", f) for f in os.listdir(os.path.join(_DIR, "csrc"))
-            if f.endswith((".hip", ".cuh", ".hpp", ".inc"))]
+            if f.endswith((".hip", ".hpp", ".inc"))]
     srcs.append(os.path.join(_DIR, "..", "include", "shielder_hip.h"))
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:

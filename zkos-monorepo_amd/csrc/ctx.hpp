@@ -6,7 +6,7 @@
 #include <mutex>
 
 #include "common.hpp"
-#include "field.cuh"
+#include "field.hip.hpp"
 
 namespace shp {
 

@@ -5,7 +5,7 @@
 // 8M + 2S against 7M + 4S for Jacobian, and needs no field inversion until the host
 // normalises the handful of final sums.
 #pragma once
-#include "field.cuh"
+#include "field.hip.hpp"
 
 namespace shp {
 

@@ -6,7 +6,7 @@
 #include <thread>
 
 #include "ctx.hpp"
-#include "curve.cuh"
+#include "curve.hip.hpp"
 
 namespace shp {
 

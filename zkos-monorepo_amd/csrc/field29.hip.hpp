@@ -1,7 +1,7 @@
 // BN254 Fq in 9 UNSATURATED 29-bit limbs, for the point additions of the MSM kernels (device only).
 //
 // Why a second representation: on gfx950 every integer VALU instruction costs the same four cycles, so a Montgomery
-// product is priced by its instruction count.  With saturated 32-bit limbs (field.cuh) each of the 128 partial products is
+// product is priced by its instruction count.  With saturated 32-bit limbs (field.hip.hpp) each of the 128 partial products is
 // a v_mad_u64_u32 PLUS a v_addc_co_u32 for the carry out of the 64-bit accumulator.  With 29-bit limbs a column of 9 + 9
 // partial products (< 2^58 each) cannot overflow 64 bits: a partial product is ONE v_mad_u64_u32, 162 in all, and the
 // Montgomery radix 2^261 exceeds 4p by so much that no product needs a conditional subtraction.  Measured with every CU busy
@@ -12,10 +12,10 @@
 // below 2^29 ("normalised") and v below a small multiple of p that every call site tracks:
 //   mul29(a, b)  needs a < A p, b < B p with A B <= 254; returns < 2.5 p  (v = (a b + q p) / 2^261 < a b / 2^261 + p)
 //   sub29<K>(a, b) = a - b + K p needs b < (K - 1/2) p; returns < a + K p
-// Tables and results stay in the 8 x 32-bit Montgomery-2^256 form of field.cuh; conversions happen once per gathered point
+// Tables and results stay in the 8 x 32-bit Montgomery-2^256 form of field.hip.hpp; conversions happen once per gathered point
 // and once per accumulator.
 #pragma once
-#include "curve.cuh"
+#include "curve.hip.hpp"
 
 
 namespace shp {
@@ -195,7 +195,7 @@ SHP_HD Fq29 sub29(const Fq29& a, const Fq29& b, const f29::L9& kp) {
     return r;
 }
 
-// Montgomery-2^261 lazy value -> canonical Montgomery-2^256 limbs of field.cuh
+// Montgomery-2^261 lazy value -> canonical Montgomery-2^256 limbs of field.hip.hpp
 SHP_HD Fq to_fq(const Fq29& a) {
     Fq29 c;
 #pragma unroll

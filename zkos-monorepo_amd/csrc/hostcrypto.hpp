@@ -7,7 +7,7 @@
 #include <string.h>
 #include <vector>
 
-#include "field.cuh"
+#include "field.hip.hpp"
 
 namespace shp {
 

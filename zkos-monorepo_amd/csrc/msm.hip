@@ -26,7 +26,7 @@
 #include <stdlib.h>
 
 #include "engine.hpp"
-#include "field29.cuh"
+#include "field29.hip.hpp"
 
 namespace shp {
 
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const G1Aff
     }
     uint32_t cur = lo;
     uint32_t boundary = s[cur + 1];
-    // the running sum lives in the 29-bit-limb form (field29.cuh); it is converted when a run ends
+    // the running sum lives in the 29-bit-limb form (field29.hip.hpp); it is converted when a run ends
     G1X29 acc;
     acc.inf = true;
     bool first_run = true;
@@ -728,7 +728,7 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
     return r;
 }
 
-// The same sum over accumulators in the 29-bit lazy form (field29.cuh): 226 instructions per product instead of ~330,
+// The same sum over accumulators in the 29-bit lazy form (field29.hip.hpp): 226 instructions per product instead of ~330,
 // and the 256 accumulators of a workgroup are not converted back to the 8 x 32-bit form first (four products each) --
 // only the one sum is.  Same rounds, same lanes; every value keeps the accumulator bounds of g1_add29.  Slots carry an
 // identity flag of their own (a lazy zz has no canonical zero).

@@ -12,7 +12,7 @@
 #include <string.h>
 #include <vector>
 
-#include "poseidon2.cuh"
+#include "poseidon2.hip.hpp"
 
 namespace shp {
 

@@ -1,7 +1,7 @@
 // Poseidon2 t=8 permutation body shared by the device kernels and the host witness generator.
 // Round structure: /root/reference/poseidon2-solidity/generate_t8.py:474-588.
 #pragma once
-#include "field.cuh"
+#include "field.hip.hpp"
 #include "poseidon2_constants.inc"
 
 namespace shp {

@@ -19,8 +19,8 @@
 #include <mutex>
 #include <thread>
 
-#include "prover_kernels.cuh"
-#include "poseidon2.cuh"
+#include "prover_kernels.hip.hpp"
+#include "poseidon2.hip.hpp"
 #include "verify.hpp"
 
 using namespace shp;
@@ -872,7 +872,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     auto V = [&](uint32_t idx) { return pr->vals + (size_t)idx * n; };
     auto PL = [&](uint32_t idx) { return pr->polys + (size_t)idx * n; };
     auto CS = [&](uint32_t idx) { return pr->cos + (size_t)idx * ne; };
-    // product scans over `cnt` vectors of n elements (prover_kernels.cuh "product scans")
+    // product scans over `cnt` vectors of n elements (prover_kernels.hip.hpp "product scans")
     const uint32_t sbs = std::min<uint32_t>(SCAN_THREADS, n), snb = n / sbs;
     Fr* const sc_ta = pr->sc_tot;
     Fr* const sc_tb = pr->sc_tot + (size_t)pr->sc_cnt * SCAN_THREADS;

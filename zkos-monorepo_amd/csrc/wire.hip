@@ -13,7 +13,7 @@
 #include <vector>
 
 #include "common.hpp"
-#include "field.cuh"
+#include "field.hip.hpp"
 
 namespace {
 
