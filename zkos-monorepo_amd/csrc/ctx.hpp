@@ -64,10 +64,6 @@ struct NttOpts {
     // with coefficient i scaled by twist[(b % twist_count) * 2^log_n + i] (= c_j^i: values on the coset c_j * H)
     const Fr* twist = nullptr;
     uint32_t twist_count = 0;
-    // the launch shares the GPU with other streams' kernels: 512-thread tiles (two butterflies per thread and stage)
-    // whatever its size -- the 1024-thread tiles of small launches buy latency with barrier and issue overhead
-    // (a pool of proving lanes: 1880 -> 1907 proofs/s)
-    bool throughput = false;
 };
 // `tmp`: caller-owned ping-pong buffer of batch * 2^log_n elements (needed when log_n > 11);
 // nullptr = the context's shared buffer (single-stream use only)

@@ -8,7 +8,7 @@
 // Design (HBM-bound shape, integer-ALU-bound in practice):
 //   * N = L1 * L2 [* L3].  One pass per digit; a pass moves every element HBM -> LDS -> HBM
 //     exactly once, so a transform costs P x 64 B/element of traffic with P in {1,2,3}.
-//   * A workgroup owns a 2048-element LDS tile (64 KiB, two 16-byte planes so that
+//   * A workgroup owns a 512- or 1024-element LDS tile (two 16-byte planes so that
 //     ds_read_b128/ds_write_b128 are lane-contiguous and bank-conflict free) holding 2^c
 //     independent length-2^s sub-transforms whose elements are ADJACENT in memory: every
 //     global access is a run of 2^c * 32 B >= 128 B.
@@ -26,7 +26,11 @@
 
 namespace shp {
 
-constexpr int NTT_TILE_LOG = 11;
+// Tile sizes: 512 elements (16 KiB of LDS, 256 threads) for domains up to 2^18 -- two passes of at most nine stages, and
+// nine or ten tiles per CU at different stages hide each other's barriers (the prover's 2^13 transforms: pool 1915 ->
+// 1955 proofs/s, a lone proof 2.0 -> 1.9 ms against 2048-element tiles) -- and 1024 elements (512 threads) above, where
+// the longer runs of adjacent elements pay (2^22: 0.63 ms against 0.645 / 0.65 for 512 / 2048; 2^24: 2.51 / 2.60 / 2.47).
+constexpr int NTT_TILE_SMALL = 9, NTT_TILE_LARGE = 10;
 
 struct PassParams {
     const Fr* src;
@@ -69,13 +73,11 @@ __device__ __forceinline__ void gstore(Fr* p, const Fr& v) {
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-// THREADS = 512 when the launch has workgroups to spare (4 elements per thread), 1024 for the prover's
-// small batches (2 elements per thread: the same work on four times the waves, a quarter of the
-// dependent chain per stage -- these launches are bound by the issue rate of a lone wave)
-template <int THREADS>
+// one butterfly per thread and stage: THREADS = half the tile
+template <int THREADS, int TILE_LOG>
 __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
-    __shared__ uint4 sh_lo[1 << NTT_TILE_LOG];
-    __shared__ uint4 sh_hi[1 << NTT_TILE_LOG];
+    __shared__ uint4 sh_lo[1 << TILE_LOG];
+    __shared__ uint4 sh_hi[1 << TILE_LOG];
     const uint32_t tid = threadIdx.x;
     const uint32_t tile = blockIdx.x;
     const uint32_t poly = p.is_first && p.src_div > 1 ? blockIdx.y / p.src_div : blockIdx.y;
@@ -298,12 +300,13 @@ static void ntt_launch_with(shp_ctx* ctx, const NttTables& T, uint32_t tw_shift,
     const size_t N = (size_t)1 << log_n;
     const int dir = o.inverse ? 1 : 0;
 
+    const uint32_t tile_log = log_n <= 2 * NTT_TILE_SMALL ? NTT_TILE_SMALL : NTT_TILE_LARGE;
     uint32_t digits[3] = {0, 0, 0};
     int P;
-    if (log_n <= NTT_TILE_LOG) {
+    if (log_n <= tile_log) {
         P = 1;
         digits[0] = log_n;
-    } else if (log_n <= 18) {
+    } else if (log_n <= 2 * tile_log) {
         P = 2;
         digits[1] = log_n / 2;
         digits[0] = log_n - digits[1];
@@ -335,10 +338,10 @@ static void ntt_launch_with(shp_ctx* ctx, const NttTables& T, uint32_t tw_shift,
         if (p.is_final) {
             if (P == 2) p.s1 = digits[0];
             if (P == 3) { p.s1 = digits[0]; p.s2 = digits[1]; }
-            uint32_t cmax = NTT_TILE_LOG - p.s;
+            uint32_t cmax = tile_log - p.s;
             p.c = cmax < p.s1 ? cmax : p.s1;
         } else {
-            uint32_t cmax = NTT_TILE_LOG - p.s;
+            uint32_t cmax = tile_log - p.s;
             p.c = cmax < p.lo_bits ? cmax : p.lo_bits;
         }
         p.h = T.h;
@@ -360,16 +363,10 @@ static void ntt_launch_with(shp_ctx* ctx, const NttTables& T, uint32_t tw_shift,
         if (p.is_final) { p.dst = d_out; p.dst_stride = N; }
         else { p.dst = tmp; p.dst_stride = N; }
         uint32_t tiles = (uint32_t)(N >> (p.s + p.c));
-        static const int forced = getenv("SHP_NTT_THREADS") ? atoi(getenv("SHP_NTT_THREADS")) : 0;   // tuning aid
-        int threads = (uint64_t)tiles * batch <= (uint64_t)4 * ctx->num_cus ? 1024 : 512;   // measured: 2^24 3.07 ms (256) / 2.82 (512) / 3.02 (1024)
-        if (o.throughput) threads = 512;
-        if (forced == 256 || forced == 512 || forced == 1024) threads = forced;
-        if (threads == 1024)
-            hipLaunchKernelGGL(ntt_pass_kernel<1024>, dim3(tiles, batch), dim3(1024), 0, st, p);
-        else if (threads == 512)
-            hipLaunchKernelGGL(ntt_pass_kernel<512>, dim3(tiles, batch), dim3(512), 0, st, p);
+        if (tile_log == NTT_TILE_SMALL)
+            hipLaunchKernelGGL((ntt_pass_kernel<256, NTT_TILE_SMALL>), dim3(tiles, batch), dim3(256), 0, st, p);
         else
-            hipLaunchKernelGGL(ntt_pass_kernel<256>, dim3(tiles, batch), dim3(256), 0, st, p);
+            hipLaunchKernelGGL((ntt_pass_kernel<512, NTT_TILE_LARGE>), dim3(tiles, batch), dim3(512), 0, st, p);
         SHP_HIP(hipGetLastError());
         consumed += p.s;
     }

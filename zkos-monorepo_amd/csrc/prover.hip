@@ -1128,7 +1128,6 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     inv.inverse = true;
     NttOpts ext;                                         // values on the nc cosets of the quotient domain
     ext.twist = pk->twist; ext.twist_count = pk->nc;
-    inv.throughput = ext.throughput = pr->throughput;
     ntt_launch(ctx, pr->vals, pr->polys, k, NV + 1, inv, st, pr->ntt_tmp);
     ntt_launch(ctx, pr->polys, pr->cos, k, (NV + 1) * pk->nc, ext, st, pr->ntt_tmp);
     // ---- P10: quotient
@@ -1247,7 +1246,6 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)jobs.size()), dim3(EVAL_THREADS), 0, st, pr->jobs, pr->pw, n, evals);
     // Lagrange values of hx and the random polynomial for the evaluation-form opening
     NttOpts fwd;
-    fwd.throughput = pr->throughput;
     ntt_launch(ctx, pr->hx, pr->lag2, k, 2, fwd, st, pr->ntt_tmp);   // out of place: hx | rand_poly are adjacent
     sync_stream(st);
     std::map<std::pair<PolyKey, int32_t>, Fr> ev;
