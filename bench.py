@@ -426,7 +426,7 @@ def micro_block(shp, ctx, sizes):
             ctx.ntt(t, lg)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        passes = 1 if lg <= 9 else 2 if lg <= 18 else 3
+        passes = 1 if lg <= 9 else 2 if lg <= 20 else 3          # 512-element tiles up to 2^18, 1024-element tiles above
         out["ntt"].append({"log_n": lg, "ms": ms, "alg_GBps": 64.0 * n / ms / 1e6, "hbm_frac": 64.0 * n / ms / 1e6 / HBM_PEAK_GBPS,
                            "passes": passes, "moved_GBps": 64.0 * n * passes / ms / 1e6,
                            "butterflies_per_s": (n / 2) * lg / (ms * 1e-3)})
