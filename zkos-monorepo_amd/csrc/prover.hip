@@ -88,7 +88,7 @@ struct shp_pk {
     Fr *fixed_vals = nullptr, *fixed_polys = nullptr, *fixed_cos = nullptr;
     Fr *sigma_vals = nullptr, *sigma_polys = nullptr, *sigma_cos = nullptr;
     Fr *l0 = nullptr, *l_last = nullptr, *l_active = nullptr;
-    Fr *x_ext = nullptr, *omegas = nullptr, *t_inv = nullptr, *consts = nullptr;
+    Fr *x_ext = nullptr, *omegas = nullptr, *consts = nullptr;
     Instr* gate_prog = nullptr;
     void (*gate_fn)(ProgArgs) = nullptr;           // the compiled gate program, when the plan is one the library ships
     std::vector<Instr*> lk_in_prog, lk_tab_prog;
@@ -283,7 +283,6 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
             node[j] = Fr::pow_u64(cj[j], n);
             ti[j] = Fr::inv(node[j] - Fr::one());
         }
-        pk->t_inv = pk->dupload(ti);
         std::vector<Fr> A((size_t)nc * nc), I((size_t)nc * nc, Fr::zero());
         for (uint32_t j = 0; j < nc; j++) {
             Fr p = Fr::one();
@@ -313,7 +312,11 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
                 }
             }
         }
-        pk->vinv = pk->dupload(I);                 // h_m = sum_j vinv[m][j] * y_j
+        // the division by the vanishing polynomial is a constant per coset (1 / (c_j^n - 1)) and everything between the
+        // numerator and the solve is linear: folded into column j of the inverse matrix, it costs nothing per proof
+        for (uint32_t m = 0; m < nc; m++)
+            for (uint32_t j = 0; j < nc; j++) I[(size_t)m * nc + j] = I[(size_t)m * nc + j] * ti[j];
+        pk->vinv = pk->dupload(I);                 // h_m = sum_j vinv[m][j] * y_j / (c_j^n - 1)
     }
     pk->consts = pk->dupload(P.consts);
     pk->gate_prog = pk->dupload(P.gate_prog);
@@ -1023,6 +1026,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     const Fr theta = tr.squeeze();
 
     ProgArgs pa;
+    pa.out_raw = nullptr;
     pa.consts = pk->consts;
     pa.adv_q = pk->adv_q; pa.fix_q = pk->fix_q; pa.inst_q = pk->inst_q;
     auto lagrange_domain = [&](ProgArgs& a) {
@@ -1046,15 +1050,15 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             lagrange_domain(pa);
             pa.mult = theta; pa.acc_in = nullptr;
             pa.prog = pk->lk_in_prog[l]; pa.n_instr = (uint32_t)lk.in_prog.size(); pa.nslots = lk.in_slots;
+            // the compressed expressions in Montgomery form and, for the sort, as plain integers in the same pass
             pa.out = pr->cin + (size_t)l * n;
+            pa.out_raw = pr->sort_raw + (size_t)(2 * l) * n;
             launch_prog(st, pa, n, pr->throughput);
             pa.prog = pk->lk_tab_prog[l]; pa.n_instr = (uint32_t)lk.tab_prog.size(); pa.nslots = lk.tab_slots;
             pa.out = pr->ctab + (size_t)l * n;
+            pa.out_raw = pr->sort_raw + (size_t)(2 * l + 1) * n;
             launch_prog(st, pa, n, pr->throughput);
-            hipLaunchKernelGGL(to_raw_kernel, dim3(ceil_div(u, 256)), dim3(256), 0, st, pr->cin + (size_t)l * n,
-                               pr->sort_raw + (size_t)(2 * l) * n, u);
-            hipLaunchKernelGGL(to_raw_kernel, dim3(ceil_div(u, 256)), dim3(256), 0, st, pr->ctab + (size_t)l * n,
-                               pr->sort_raw + (size_t)(2 * l + 1) * n, u);
+            pa.out_raw = nullptr;
         }
         pr->timers.begin(KID_RANK_SORT, st);
         SHP_REQUIRE(2 * L <= pr->sc_cnt, SHP_ERR_INVALID_ARG, "prove: too many lookups for the sort scratch");
@@ -1170,7 +1174,6 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         q.mask = n - 1; q.y = y; q.beta = beta; q.gamma = gamma; q.h = pr->h;
         hipLaunchKernelGGL(lookup_quotient_kernel, dim3(ne / ebs), dim3(ebs), 0, st, q);
     }
-    hipLaunchKernelGGL(scale_periodic_kernel, dim3(ne / ebs), dim3(ebs), 0, st, pr->h, pk->t_inv, k);
     // per-coset interpolants, then the nc x nc solve per coefficient: the quotient pieces [nc][n] (in the buffer
     // the lookup compression no longer needs)
     ntt_launch(ctx, pr->h, pr->h, k, pk->nc, inv, st, pr->ntt_tmp);

@@ -46,6 +46,7 @@ struct ProgArgs {
     Fr mult;
     const Fr* acc_in;
     Fr* out;
+    Fr* out_raw;      // optional second copy of the result as a plain integer (out of Montgomery form), for the sort keys
 };
 
 constexpr int PROG_THREADS = 64;
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(PROG_THREADS) void prog_fold_kernel(ProgArgs a) {
         }
     }
     st(a.out + row, acc);
+    if (a.out_raw) st(a.out_raw + row, acc.to_raw());
 }
 
 // The same program with the slot file in VECTOR REGISTERS (plans with <= 16 slots): one 16-wide register vector
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(PROG_THREADS) void prog_fold_reg_kernel(ProgArgs a)
         put(dst & 15u, r);
     }
     st(a.out + row, acc);
+    if (a.out_raw) st(a.out_raw + row, acc.to_raw());
 }
 
 // rows [r0, r1) of every column (blockIdx.y) to zero: what a previous proof assigned beyond this proof's rows
@@ -689,12 +692,6 @@ __global__ void lookup_quotient_kernel(LookupQArgs a) {
     h = h * a.y + l0 * d;
     h = h * a.y + la * d * (ap - ld(a.pin + iprev));
     st(a.h + i, h);
-}
-
-// h on coset j (rows j * n .. j * n + n - 1) times 1 / (c_j^n - 1): the vanishing polynomial is constant on a coset
-__global__ void scale_periodic_kernel(Fr* h, const Fr* t_inv, uint32_t log_n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    st(h + i, ld(h + i) * ld(t_inv + (i >> log_n)));
 }
 
 // Quotient pieces from the per-coset interpolants.  q_j = iNTT of h on coset c_j * H, so q_j[t] = c_j^t * sum_m
