@@ -655,6 +655,7 @@ struct shp_prover {
     Fr *sc_pre = nullptr, *sc_suf = nullptr;                   // [SC][n] block-local scans
     Fr *sc_tot = nullptr;                                      // [6][SC][nb]: tot_a, tot_b, bpre_a, bsuf_b | [SC] inv
     uint32_t sc_cnt = 0;
+    uint32_t* sc_done = nullptr;                               // [SC] workgroups of a product scan that have stored their totals
     std::vector<void*> owned;
     template <class T>
     T* dalloc(size_t count) {
@@ -745,6 +746,8 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->sc_pre = pr->dalloc<Fr>((size_t)pr->sc_cnt * n);
     pr->sc_suf = pr->dalloc<Fr>((size_t)pr->sc_cnt * n);
     pr->sc_tot = pr->dalloc<Fr>((size_t)5 * pr->sc_cnt * SCAN_THREADS);
+    pr->sc_done = pr->dalloc<uint32_t>(pr->sc_cnt);            // zero between launches: the last workgroup resets its counter
+    SHP_HIP(hipMemset(pr->sc_done, 0, pr->sc_cnt * sizeof(uint32_t)));
     pr->msm_ws.timers = &pr->timers;
     pr->wscratch.assign(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
     {
@@ -890,9 +893,9 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         il.n = 0;
         const bool on_host = !pr->throughput && cnt <= INV_LIST_MAX;
         Fr* totals = on_host ? (Fr*)pr->stage_alloc(cnt * sizeof(Fr)) : nullptr;
-        hipLaunchKernelGGL(scan_local_kernel, dim3(snb, cnt), dim3(sbs), 0, st, a, b, n, pr->sc_pre, pr->sc_suf, sc_ta, sc_tb);
-        hipLaunchKernelGGL(scan_totals_kernel, dim3(cnt), dim3(SCAN_THREADS), 0, st, sc_ta, sc_tb, snb, sc_bpre, sc_bsuf, sc_inv,
-                           totals);
+        ScanTotals T;
+        T.bpre_a = sc_bpre; T.bsuf_b = sc_bsuf; T.inv_b = sc_inv; T.total_out = totals; T.done = pr->sc_done;
+        hipLaunchKernelGGL(scan_local_kernel, dim3(snb, cnt), dim3(sbs), 0, st, a, b, n, pr->sc_pre, pr->sc_suf, sc_ta, sc_tb, T);
         if (on_host) {
             sync_stream(st);
             il.n = cnt;

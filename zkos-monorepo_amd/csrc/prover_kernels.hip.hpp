@@ -257,10 +257,10 @@ __device__ __forceinline__ Fr block_scan_bwd_excl(Fr v, Fr* sh, uint32_t t, uint
 
 // ------------------------------------------------------------------ product scans over many workgroups
 // Prefix products of `a` and suffix products of `b` over `cnt` products of `n` elements each, in
-// three short launches instead of one long single-workgroup chain:
-//   scan_local   every min(256, n)-element block: exclusive prefix of a, inclusive suffix of b, block totals
-//   scan_totals  one workgroup per product: exclusive prefix / suffix of the block totals and the
-//                ONE inversion of the product of all b (binary Euclid, Fp::inv)
+// two short launches instead of one long single-workgroup chain:
+//   scan_local   every min(256, n)-element block: exclusive prefix of a, inclusive suffix of b, block totals; the
+//                workgroup that stores a product's last totals goes on with scan_totals_body: exclusive prefix /
+//                suffix of the block totals and the ONE inversion of the product of all b (Kaliski, Fp::inv)
 //   apply        element-wise (grand_product_apply / batch_invert_apply)
 constexpr int SCAN_THREADS = 256;
 
@@ -285,9 +285,17 @@ __device__ __forceinline__ Fr shfl_fr(const Fr& v, int src) {
 
 // grid (n / bs, cnt), bs = blockDim.x = min(256, n).
 // pre_a[i] = prod_{block start <= r < i} a_r ; suf_b[i] = prod_{i <= r < block end} b_r
+__device__ __forceinline__ void scan_totals_body(const Fr* tot_a, const Fr* tot_b, uint32_t nb, Fr* bpre_a, Fr* bsuf_b, Fr* inv_b,
+                                                 Fr* total_out, uint32_t p, Fr* sh);
+struct ScanTotals {          // what the last workgroup of a product does with the block totals (scan_totals_body)
+    Fr *bpre_a, *bsuf_b, *inv_b, *total_out;
+    uint32_t* done;          // per product: workgroups that have stored their totals (zero between launches)
+};
 __global__ __launch_bounds__(SCAN_THREADS) void scan_local_kernel(const Fr* a, const Fr* b, uint32_t n, Fr* pre_a, Fr* suf_b,
-                                                                  Fr* tot_a, Fr* tot_b) {
+                                                                  Fr* tot_a, Fr* tot_b, ScanTotals T) {
     __shared__ Fr wa[SCAN_THREADS / 64], wb[SCAN_THREADS / 64];
+    __shared__ Fr sh_tot[SCAN_THREADS];
+    __shared__ uint32_t is_last;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, bs = blockDim.x, nw = bs >> 6;
     const size_t i = (size_t)blockIdx.y * n + (size_t)blockIdx.x * bs + t;
     const Fr va = ld(a + i), vb = ld(b + i);
@@ -313,17 +321,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_local_kernel(const Fr* a, c
         for (uint32_t w = 1; w < nw; w++) { ta = ta * wa[w]; tb = tb * wb[w]; }
         st(tot_a + (size_t)blockIdx.y * nb + blockIdx.x, ta);
         st(tot_b + (size_t)blockIdx.y * nb + blockIdx.x, tb);
+        // the workgroup that stores a product's last totals scans them (and inverts their product): no second dispatch.
+        // Device-scope fences on both sides of the count: the other workgroups may have run on other XCDs.
+        __threadfence();
+        is_last = atomicAdd(T.done + blockIdx.y, 1u) + 1 == nb;
     }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (t == 0) T.done[blockIdx.y] = 0;
+    scan_totals_body(tot_a, tot_b, n / bs, T.bpre_a, T.bsuf_b, T.inv_b, T.total_out, blockIdx.y, sh_tot);
 }
 
-// grid (cnt), 256 threads, nb = n / 256 <= 256 block totals per product.
+// One workgroup of 256 threads (or one wave when nb <= 64) for product p, nb = n / 256 <= 256 block totals per product.
 // bpre_a[k] = prod_{j<k} tot_a[j]; bsuf_b[k] = prod_{j>k} tot_b[j]; inv_b = 1 / prod_j tot_b[j]
 // total_out (pinned host memory) non-null: the product of all b goes there instead of its inverse into inv_b --
 // a lone proof inverts it on the host (3 us + a stream round trip) rather than on one GPU lane (55 us)
-__global__ __launch_bounds__(SCAN_THREADS) void scan_totals_kernel(const Fr* tot_a, const Fr* tot_b, uint32_t nb, Fr* bpre_a,
-                                                                   Fr* bsuf_b, Fr* inv_b, Fr* total_out) {
-    __shared__ Fr sh[SCAN_THREADS];
-    const uint32_t t = threadIdx.x, p = blockIdx.x;
+__device__ __forceinline__ void scan_totals_body(const Fr* tot_a, const Fr* tot_b, uint32_t nb, Fr* bpre_a, Fr* bsuf_b, Fr* inv_b,
+                                                 Fr* total_out, uint32_t p, Fr* sh /* [SCAN_THREADS] */) {
+    const uint32_t t = threadIdx.x;
     if (nb <= 64) {
         // the usual case (n <= 2^14): one wave, both scans by shuffles in one pass, no barriers
         if (t >= 64) return;
