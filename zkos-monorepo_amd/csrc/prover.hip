@@ -636,7 +636,7 @@ struct shp_prover {
     Fr* pw = nullptr;
     EvalJob* jobs = nullptr;                                   // fixed per prover (buffer addresses, point indices): uploaded once
     bool jobs_uploaded = false;
-    Fr *fsets = nullptr, *pdiff = nullptr, *dinv = nullptr, *wvals = nullptr, *mdiff = nullptr;
+    Fr *fsets = nullptr, *dinv = nullptr, *wvals = nullptr, *mdiff = nullptr;
     ShplonkArgs* shp_args = nullptr;                           // one arena: the SHPLONK arguments, then the rotation
     LincombArgs* lin = nullptr;                                // sets' combinations right behind them (one upload)
     Fr* ntt_tmp = nullptr;
@@ -730,10 +730,9 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->pw = pr->dalloc<Fr>((size_t)MAX_POINTS * n);
     pr->jobs = pr->dalloc<EvalJob>(512);
     pr->fsets = pr->dalloc<Fr>((size_t)MAX_SETS * n);
-    pr->pdiff = pr->dalloc<Fr>((size_t)MAX_POINTS * n);
     pr->dinv = pr->dalloc<Fr>((size_t)MAX_POINTS * n);
     pr->wvals = pr->dalloc<Fr>((size_t)2 * n);
-    pr->mdiff = pr->dalloc<Fr>((size_t)2 * n);
+    pr->mdiff = pr->dalloc<Fr>((size_t)n);                     // 1 / (omega^r - mu)
     static_assert(sizeof(ShplonkArgs) % 8 == 0, "LincombArgs follows ShplonkArgs in one arena");
     pr->shp_args = (ShplonkArgs*)pr->dalloc<uint8_t>(sizeof(ShplonkArgs) + MAX_SETS * sizeof(LincombArgs));
     pr->lin = (LincombArgs*)((uint8_t*)pr->shp_args + sizeof(ShplonkArgs));
@@ -888,13 +887,15 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     // A lone proof (latency mode) inverts the totals on the host: the product goes to pinned memory, the stream is
     // drained, the inverses come back as kernel arguments.  Pool lanes keep the inversion on the device (one lane,
     // 55 us, but no extra round trip while fifteen other lanes fill the GPU).
-    auto product_scans = [&](const Fr* a, const Fr* b, uint32_t cnt) -> InvList {
+    // diff_points non-null: product p runs over omega^r - diff_points[p] (a and b are not read)
+    auto product_scans = [&](const Fr* a, const Fr* b, uint32_t cnt, const Fr* diff_points = nullptr) -> InvList {
         InvList il;
         il.n = 0;
         const bool on_host = !pr->throughput && cnt <= INV_LIST_MAX;
         Fr* totals = on_host ? (Fr*)pr->stage_alloc(cnt * sizeof(Fr)) : nullptr;
         ScanTotals T;
         T.bpre_a = sc_bpre; T.bsuf_b = sc_bsuf; T.inv_b = sc_inv; T.total_out = totals; T.done = pr->sc_done;
+        T.omegas = diff_points ? pk->omegas : nullptr; T.points = diff_points;
         hipLaunchKernelGGL(scan_local_kernel, dim3(snb, cnt), dim3(sbs), 0, st, a, b, n, pr->sc_pre, pr->sc_suf, sc_ta, sc_tb, T);
         if (on_host) {
             sync_stream(st);
@@ -903,9 +904,10 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         }
         return il;
     };
-    auto batch_invert = [&](const Fr* in, Fr* out, uint32_t cnt) {
+    // out[p][r] = 1 / (omega^r - points[p])
+    auto invert_point_diffs = [&](const Fr* points, Fr* out, uint32_t cnt) {
         pr->timers.begin(KID_BATCH_INVERT, st);
-        const InvList il = product_scans(in, in, cnt);
+        const InvList il = product_scans(nullptr, nullptr, cnt, points);
         hipLaunchKernelGGL(batch_invert_apply_kernel, dim3(snb, cnt), dim3(sbs), 0, st, pr->sc_pre, pr->sc_suf, sc_bpre, sc_bsuf,
                            sc_inv, n, out, il);
         pr->timers.end(st);
@@ -1311,9 +1313,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         SHP_HIP(hipMemcpyAsync(pr->shp_args, blk, sizeof(sa) + lin.size() * sizeof(LincombArgs), hipMemcpyHostToDevice, st));
     }
     hipLaunchKernelGGL(lincomb_kernel, dim3(ceil_div(n, 256), (uint32_t)sets.size()), dim3(256), 0, st, pr->lin, n, pr->fsets);
-    hipLaunchKernelGGL(point_diff_kernel, dim3(ceil_div(n, 256), (uint32_t)points.size()), dim3(256), 0, st, pk->omegas,
-                       d_points, n, pr->pdiff);
-    batch_invert(pr->pdiff, pr->dinv, (uint32_t)points.size());
+    invert_point_diffs(d_points, pr->dinv, (uint32_t)points.size());
     hipLaunchKernelGGL(shplonk_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals);
     commit(srs->msm_gl, pr->wvals, 1, pts.data());
     tr.write_point(pts[0].x, pts[0].y);
@@ -1331,22 +1331,21 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     }
     const Fr d0inv = Fr::inv(diffs[0]);
     nu_pow = Fr::one();
-    sa.c0 = Fr::zero();
+    ShplonkWpArgs wp;
+    wp.c0 = Fr::zero();
     for (size_t i = 0; i < sets.size(); i++) {
         Fr rmu = Fr::zero();
         for (size_t t = rcoefs[i].size(); t-- > 0;) rmu = rmu * mu + rcoefs[i][t];
-        sa.coef[i] = nu_pow * diffs[i] * d0inv;
-        sa.c0 = sa.c0 + sa.coef[i] * rmu;
+        wp.coef[i] = nu_pow * diffs[i] * d0inv;
+        wp.c0 = wp.c0 + wp.coef[i] * rmu;
         nu_pow = nu_pow * nu;
     }
-    sa.c1 = zt * d0inv;
-    sa.w = pr->wvals;
-    sa.minv = pr->mdiff + n;
-    h2d(pr->shp_args, &sa, sizeof(sa));
+    for (size_t i = sets.size(); i < (size_t)MAX_SETS; i++) wp.coef[i] = Fr::zero();
+    wp.c1 = zt * d0inv;
+    wp.n_sets = sa.n_sets; wp.f = pr->fsets; wp.w = pr->wvals; wp.minv = pr->mdiff;
     const Fr* d_mu = (const Fr*)staged(&mu, sizeof(Fr));
-    hipLaunchKernelGGL(point_diff_kernel, dim3(ceil_div(n, 256), 1), dim3(256), 0, st, pk->omegas, d_mu, n, pr->mdiff);
-    batch_invert(pr->mdiff, pr->mdiff + n, 1);
-    hipLaunchKernelGGL(shplonk_wp_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals + n);
+    invert_point_diffs(d_mu, pr->mdiff, 1);
+    hipLaunchKernelGGL(shplonk_wp_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, wp, n, pr->wvals + n);
     commit(srs->msm_gl, pr->wvals + n, 1, pts.data());
     tr.write_point(pts[0].x, pts[0].y);
     pc.mark("Wprime");

@@ -290,6 +290,9 @@ __device__ __forceinline__ void scan_totals_body(const Fr* tot_a, const Fr* tot_
 struct ScanTotals {          // what the last workgroup of a product does with the block totals (scan_totals_body)
     Fr *bpre_a, *bsuf_b, *inv_b, *total_out;
     uint32_t* done;          // per product: workgroups that have stored their totals (zero between launches)
+    // non-null: the factors of product p are omega^r - points[p] (the denominators of the SHPLONK quotients), formed
+    // here instead of being read from a and b
+    const Fr *omegas, *points;
 };
 __global__ __launch_bounds__(SCAN_THREADS) void scan_local_kernel(const Fr* a, const Fr* b, uint32_t n, Fr* pre_a, Fr* suf_b,
                                                                   Fr* tot_a, Fr* tot_b, ScanTotals T) {
@@ -298,7 +301,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_local_kernel(const Fr* a, c
     __shared__ uint32_t is_last;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, bs = blockDim.x, nw = bs >> 6;
     const size_t i = (size_t)blockIdx.y * n + (size_t)blockIdx.x * bs + t;
-    const Fr va = ld(a + i), vb = ld(b + i);
+    Fr va, vb;
+    if (T.omegas) {
+        va = ld(T.omegas + (size_t)blockIdx.x * bs + t) - ld(T.points + blockIdx.y);
+        vb = va;
+    } else {
+        va = ld(a + i);
+        vb = ld(b + i);
+    }
     Fr ia = va, sb = vb;                   // inclusive prefix of a / inclusive suffix of b inside the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -794,24 +804,15 @@ __global__ void lincomb_kernel(const LincombArgs* args, uint32_t n, Fr* out) {
 }
 
 // d[p][i] = omega^i - point_p
-__global__ void point_diff_kernel(const Fr* omegas, const Fr* points, uint32_t n, Fr* d) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    st(d + (size_t)blockIdx.y * n + i, ld(omegas + i) - ld(points + blockIdx.y));
-}
-
 struct ShplonkArgs {
     uint32_t n_sets;
     uint32_t n_rots[MAX_SETS];
     uint32_t rot_pt[MAX_SETS][MAX_SET_ROTS];     // index of the set's points in `dinv`
     Fr rcoef[MAX_SETS][MAX_SET_ROTS];            // R_i coefficients, low to high
-    Fr coef[MAX_SETS];                           // nu^i  (W)   |  nu^i diff_i / diff_0  (W')
-    Fr c0, c1;                                   // W': sum_i coef_i R_i(mu), Z_T(mu) / diff_0
+    Fr coef[MAX_SETS];                           // nu^i
     const Fr* f;                                 // [n_sets][n] combined set polynomials (values)
     const Fr* dinv;                              // [points][n] 1 / (omega^r - point)
     const Fr* omegas;                            // omega^r
-    const Fr* w;                                 // W values (W' only)
-    const Fr* minv;                              // 1 / (omega^r - mu) (W' only)
 };
 
 // W(omega^r) = sum_i nu^i (f_i - R_i)(omega^r) / Z_i(omega^r)
@@ -831,8 +832,15 @@ __global__ void shplonk_w_kernel(const ShplonkArgs* ap, uint32_t n, Fr* out) {
 }
 
 // W'(omega^r) = (sum_i coef_i f_i(omega^r) - c0 - c1 W(omega^r)) / (omega^r - mu)
-__global__ void shplonk_wp_kernel(const ShplonkArgs* ap, uint32_t n, Fr* out) {
-    const ShplonkArgs& a = *ap;
+struct ShplonkWpArgs {                           // by value: a few hundred bytes of kernel arguments, no upload
+    uint32_t n_sets;
+    Fr coef[MAX_SETS];                           // nu^i diff_i / diff_0
+    Fr c0, c1;                                   // sum_i coef_i R_i(mu), Z_T(mu) / diff_0
+    const Fr* f;                                 // [n_sets][n] combined set polynomials (values)
+    const Fr* w;                                 // W values
+    const Fr* minv;                              // 1 / (omega^r - mu)
+};
+__global__ void shplonk_wp_kernel(ShplonkWpArgs a, uint32_t n, Fr* out) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     Fr acc = Fr::zero();
