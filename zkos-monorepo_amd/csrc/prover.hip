@@ -158,22 +158,26 @@ static GateKernelFn find_gate_kernel(const PlanData& P) {
     return nullptr;
 }
 
-static void launch_prog(hipStream_t st, const ProgArgs& a, uint32_t size, bool throughput) {
+// `b` non-null: a second program of the same size in the same launch
+static void launch_prog(hipStream_t st, const ProgArgs& a, uint32_t size, bool throughput, const ProgArgs* b = nullptr) {
     // up to 16 slots: the register-file interpreter (no LDS) for throughput lanes -- it leaves the CU's LDS to the
     // other lanes' kernels (+3 % pool throughput); a lone proof is 17 us faster with the LDS one (231 vs 214 us).
     // SHP_PROG_REG=0 / 1 forces one of them (A/B, tests)
     static const char* const force = getenv("SHP_PROG_REG");
     const bool use_reg = force ? force[0] != '0' : throughput;
-    if (use_reg && a.nslots <= 16) {
-        hipLaunchKernelGGL(prog_fold_reg_kernel, dim3(size / PROG_THREADS), dim3(PROG_THREADS), 0, st, a);
+    const ProgArgs& second = b ? *b : a;
+    const dim3 grid(size / PROG_THREADS, b ? 2 : 1);
+    const uint32_t nslots = std::max(a.nslots, second.nslots);
+    if (use_reg && nslots <= 16) {
+        hipLaunchKernelGGL(prog_fold_reg_kernel, grid, dim3(PROG_THREADS), 0, st, a, second);
         return;
     }
-    size_t lds = (size_t)a.nslots * 8 * PROG_THREADS * 4;
+    size_t lds = (size_t)nslots * 8 * PROG_THREADS * 4;
     static std::once_flag attr_once;       // lanes launch from several host threads
     std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute((const void*)prog_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 8 * PROG_THREADS * 4);
     });
-    hipLaunchKernelGGL(prog_fold_kernel, dim3(size / PROG_THREADS), dim3(PROG_THREADS), lds, st, a);
+    hipLaunchKernelGGL(prog_fold_kernel, grid, dim3(PROG_THREADS), lds, st, a, second);
 }
 
 // stored_comm: commitments read from a saved key (fixed then sigma); nullptr = compute them (MSMs)
@@ -1055,14 +1059,15 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             lagrange_domain(pa);
             pa.mult = theta; pa.acc_in = nullptr;
             pa.prog = pk->lk_in_prog[l]; pa.n_instr = (uint32_t)lk.in_prog.size(); pa.nslots = lk.in_slots;
-            // the compressed expressions in Montgomery form and, for the sort, as plain integers in the same pass
+            // the compressed expressions in Montgomery form and, for the sort, as plain integers in the same pass;
+            // input and table expression in one launch
             pa.out = pr->cin + (size_t)l * n;
             pa.out_raw = pr->sort_raw + (size_t)(2 * l) * n;
-            launch_prog(st, pa, n, pr->throughput);
-            pa.prog = pk->lk_tab_prog[l]; pa.n_instr = (uint32_t)lk.tab_prog.size(); pa.nslots = lk.tab_slots;
-            pa.out = pr->ctab + (size_t)l * n;
-            pa.out_raw = pr->sort_raw + (size_t)(2 * l + 1) * n;
-            launch_prog(st, pa, n, pr->throughput);
+            ProgArgs pt = pa;
+            pt.prog = pk->lk_tab_prog[l]; pt.n_instr = (uint32_t)lk.tab_prog.size(); pt.nslots = lk.tab_slots;
+            pt.out = pr->ctab + (size_t)l * n;
+            pt.out_raw = pr->sort_raw + (size_t)(2 * l + 1) * n;
+            launch_prog(st, pa, n, pr->throughput, &pt);
             pa.out_raw = nullptr;
         }
         pr->timers.begin(KID_RANK_SORT, st);
@@ -1106,10 +1111,12 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         pg.col[c] = t == COL_ADVICE ? V(ix) : t == COL_FIXED ? pk->fixed_vals + (size_t)ix * n : V(I_INST);
         pg.dbeta[c] = pk->delta_pow[c] * beta;
     }
-    if (S) hipLaunchKernelGGL(perm_ratio_kernel, dim3(ceil_div(n, 256), S), dim3(256), 0, st, pg, n, pr->num, pr->den);
-    if (L)
-        hipLaunchKernelGGL(lookup_ratio_kernel, dim3(ceil_div(n, 256), L), dim3(256), 0, st, pr->cin, pr->ctab, V(I_PIN),
-                           V(I_PIN + 1), (size_t)2 * n, n, beta, gamma, pr->num + (size_t)S * n, pr->den + (size_t)S * n);
+    if (S + L) {
+        LookupRatioArgs lr;
+        lr.cin = pr->cin; lr.ctab = pr->ctab; lr.pin = V(I_PIN); lr.ptab = V(I_PIN + 1); lr.pstride = (size_t)2 * n;
+        lr.beta = beta; lr.gamma = gamma;
+        hipLaunchKernelGGL(perm_ratio_kernel, dim3(ceil_div(n, 256), S + L), dim3(256), 0, st, pg, lr, S, n, pr->num, pr->den);
+    }
     hb.clear();
     for (uint32_t p = 0; p < S + L; p++) {
         for (uint32_t j = 0; j < bf; j++) hb.push_back(draw());
@@ -1168,10 +1175,10 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         pa.mult = theta; pa.acc_in = nullptr;
         pa.prog = pk->lk_in_prog[l]; pa.n_instr = (uint32_t)lk.in_prog.size(); pa.nslots = lk.in_slots;
         pa.out = pr->aux_ext;
-        launch_prog(st, pa, ne, pr->throughput);
-        pa.prog = pk->lk_tab_prog[l]; pa.n_instr = (uint32_t)lk.tab_prog.size(); pa.nslots = lk.tab_slots;
-        pa.out = pr->aux_ext + ne;
-        launch_prog(st, pa, ne, pr->throughput);
+        ProgArgs pt = pa;
+        pt.prog = pk->lk_tab_prog[l]; pt.n_instr = (uint32_t)lk.tab_prog.size(); pt.nslots = lk.tab_slots;
+        pt.out = pr->aux_ext + ne;
+        launch_prog(st, pa, ne, pr->throughput, &pt);
         LookupQArgs q;
         q.z = CS(I_LZ + l); q.pin = CS(I_PIN + 2 * l); q.ptab = CS(I_PIN + 2 * l + 1);
         q.ain = pr->aux_ext; q.stab = pr->aux_ext + ne;
@@ -1205,11 +1212,10 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     const Fr* d_points = (const Fr*)staged(points.data(), points.size() * sizeof(Fr));
     {
         uint32_t per = 1;                                   // one power per thread: the chain is the exponentiation alone
-        hipLaunchKernelGGL(powers_kernel, dim3(ceil_div(ceil_div(n, per), 256), (uint32_t)points.size()), dim3(256), 0, st,
-                           d_points, n, per, pr->pw);
+        const Fr xn = Fr::pow_u64(x, n);                    // the extra grid row combines the quotient pieces into hx
+        hipLaunchKernelGGL(powers_kernel, dim3(ceil_div(ceil_div(n, per), 256), (uint32_t)points.size() + 1), dim3(256), 0, st,
+                           d_points, (uint32_t)points.size(), n, per, pr->pw, (const Fr*)hp, npieces, xn, pr->hx);
     }
-    const Fr xn = Fr::pow_u64(x, n);
-    hipLaunchKernelGGL(combine_pieces_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, hp, n, npieces, xn, pr->hx);
     // the eval list in proof order, then h(x) (needed only for the opening argument)
     std::vector<EvalJob> jobs;
     std::vector<std::pair<PolyKey, int32_t>> job_key;

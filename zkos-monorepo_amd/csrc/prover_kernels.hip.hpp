@@ -51,7 +51,7 @@ struct ProgArgs {
 
 constexpr int PROG_THREADS = 64;
 
-__global__ __launch_bounds__(PROG_THREADS) void prog_fold_kernel(ProgArgs a) {
+__device__ __forceinline__ void prog_fold_body(const ProgArgs& a) {
     // slots as two 16-byte planes per slot, [slot][plane][lane]: one ds_read_b128 / ds_write_b128 per plane,
     // lane-contiguous (conflict free) -- a quarter of the LDS instructions of a [slot][limb][lane] layout
     extern __shared__ uint4 slots[];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(PROG_THREADS) void prog_fold_kernel(ProgArgs a) {
 // the other proving lanes.
 typedef uint32_t slotvec_t __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(PROG_THREADS) void prog_fold_reg_kernel(ProgArgs a) {
+__device__ __forceinline__ void prog_fold_reg_body(const ProgArgs& a) {
     slotvec_t L[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) L[k] = (slotvec_t)(0u);
@@ -168,6 +168,17 @@ __global__ __launch_bounds__(PROG_THREADS) void prog_fold_reg_kernel(ProgArgs a)
     if (a.out_raw) st(a.out_raw + row, acc.to_raw());
 }
 
+// One or two programs per launch (grid.y = 1 or 2, blockIdx.y selects -- by branch, not by index: a by-value argument
+// indexed at run time would be copied to scratch): the input and table halves of a lookup's compression share a dispatch.
+__global__ __launch_bounds__(PROG_THREADS) void prog_fold_kernel(ProgArgs a0, ProgArgs a1) {
+    if (blockIdx.y == 0) prog_fold_body(a0);
+    else prog_fold_body(a1);
+}
+__global__ __launch_bounds__(PROG_THREADS) void prog_fold_reg_kernel(ProgArgs a0, ProgArgs a1) {
+    if (blockIdx.y == 0) prog_fold_reg_body(a0);
+    else prog_fold_reg_body(a1);
+}
+
 // rows [r0, r1) of every column (blockIdx.y) to zero: what a previous proof assigned beyond this proof's rows
 __global__ void zero_rows_kernel(Fr* cols, size_t stride, uint32_t r0, uint32_t r1) {
     const uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
@@ -198,10 +209,27 @@ struct PermArgs {
 };
 
 // ratio numerators / denominators of permutation set s on the lagrange domain
-__global__ void perm_ratio_kernel(PermArgs a, uint32_t n, Fr* num, Fr* den) {
+struct LookupRatioArgs {
+    const Fr *cin, *ctab, *pin, *ptab;
+    size_t pstride;
+    Fr beta, gamma;
+};
+__device__ __forceinline__ void lookup_ratio_body(const LookupRatioArgs& a, uint32_t l, uint32_t i, uint32_t n, Fr* num, Fr* den) {
+    Fr nu = (ld(a.cin + (size_t)l * n + i) + a.beta) * (ld(a.ctab + (size_t)l * n + i) + a.gamma);
+    Fr de = (ld(a.pin + (size_t)l * a.pstride + i) + a.beta) * (ld(a.ptab + (size_t)l * a.pstride + i) + a.gamma);
+    st(num + (size_t)l * n + i, nu);
+    st(den + (size_t)l * n + i, de);
+}
+// grid (n / 256, n_sets + n_lookups): rows of blockIdx.y below n_sets are permutation sets, the rest lookups (their
+// ratios follow the sets' in num / den) -- one dispatch for every grand product of the proof
+__global__ void perm_ratio_kernel(PermArgs a, LookupRatioArgs lk, uint32_t n_sets, uint32_t n, Fr* num, Fr* den) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s = blockIdx.y;
     if (i >= n) return;
+    if (s >= n_sets) {
+        lookup_ratio_body(lk, s - n_sets, i, n, num + (size_t)n_sets * n, den + (size_t)n_sets * n);
+        return;
+    }
     Fr nu = Fr::one(), de = Fr::one();
     Fr x = ld(a.xs + i);
     uint32_t lo = s * a.chunk, hi = lo + a.chunk < a.n_cols ? lo + a.chunk : a.n_cols;
@@ -212,17 +240,6 @@ __global__ void perm_ratio_kernel(PermArgs a, uint32_t n, Fr* num, Fr* den) {
     }
     st(num + (size_t)s * n + i, nu);
     st(den + (size_t)s * n + i, de);
-}
-
-__global__ void lookup_ratio_kernel(const Fr* cin, const Fr* ctab, const Fr* pin, const Fr* ptab, size_t pstride,
-                                    uint32_t n, Fr beta, Fr gamma, Fr* num, Fr* den) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t l = blockIdx.y;
-    if (i >= n) return;
-    Fr nu = (ld(cin + (size_t)l * n + i) + beta) * (ld(ctab + (size_t)l * n + i) + gamma);
-    Fr de = (ld(pin + (size_t)l * pstride + i) + beta) * (ld(ptab + (size_t)l * pstride + i) + gamma);
-    st(num + (size_t)l * n + i, nu);
-    st(den + (size_t)l * n + i, de);
 }
 
 // block-wide multiplicative scans over one value per thread (Hillis-Steele in LDS)
@@ -736,9 +753,20 @@ __global__ void coset_combine_kernel(const Fr* q, const Fr* cinv, const Fr* vinv
 
 // ------------------------------------------------------------------ evaluations
 // pw[p][i] = point_p^i
-__global__ void powers_kernel(const Fr* points, uint32_t n, uint32_t per, Fr* pw) {
+// the row of blockIdx.y == n_points forms hx = sum_i x^(n i) piece_i instead (Horner over the quotient pieces): the two
+// are independent and share a dispatch
+__global__ void powers_kernel(const Fr* points, uint32_t n_points, uint32_t n, uint32_t per, Fr* pw, const Fr* pieces,
+                              uint32_t n_pieces, Fr xn, Fr* hx) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t p = blockIdx.y;
+    if (p == n_points) {
+        for (uint32_t i = t * per; i < (t + 1) * per && i < n; i++) {
+            Fr acc = Fr::zero();
+            for (int q = (int)n_pieces - 1; q >= 0; q--) acc = acc * xn + ld(pieces + (size_t)q * n + i);
+            st(hx + i, acc);
+        }
+        return;
+    }
     uint32_t i0 = t * per;
     if (i0 >= n) return;
     Fr x = ld(points + p);
@@ -771,15 +799,6 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_kernel(const EvalJob* jobs,
         for (int k = 1; k < EVAL_THREADS / 64; k++) s = s + sh[k];
         st(out + blockIdx.x, s);
     }
-}
-
-// hx = sum_i x^(n i) piece_i  (Horner over the quotient pieces)
-__global__ void combine_pieces_kernel(const Fr* pieces, uint32_t n, uint32_t count, Fr xn, Fr* out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fr acc = Fr::zero();
-    for (int p = (int)count - 1; p >= 0; p--) acc = acc * xn + ld(pieces + (size_t)p * n + i);
-    st(out + i, acc);
 }
 
 // ------------------------------------------------------------------ SHPLONK in evaluation form
