@@ -1002,30 +1002,29 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     Fr* const instcol = grid + (size_t)A * n;           // rows past the instances stay zero (cleared at creation)
     for (size_t i = 0; i < instances.size(); i++) instcol[i] = instances[i];
     // only the rows this proof assigns and the blinding rows travel; the rest is zero on both sides
-    const size_t pitch = (size_t)n * sizeof(Fr);
     if (A && rows_now < pr->dev_rows)                   // the previous proof filled more rows than this one
         hipLaunchKernelGGL(zero_rows_kernel, dim3(ceil_div(pr->dev_rows - rows_now, 256), A), dim3(256), 0, st, V(0), (size_t)n,
                            rows_now, pr->dev_rows);
     pr->dev_rows = rows_now;
-    if (A && rows_now)
-        SHP_HIP(hipMemcpy2DAsync(V(0), pitch, grid, pitch, (size_t)rows_now * sizeof(Fr), A, hipMemcpyHostToDevice, st));
-    if (A) SHP_HIP(hipMemcpy2DAsync(V(0) + u, pitch, grid + u, pitch, (size_t)(n - u) * sizeof(Fr), A, hipMemcpyHostToDevice, st));
-    if (!instances.empty())
-        SHP_HIP(hipMemcpyAsync(V(I_INST), instcol, instances.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
     Transcript tr(pk->vk_digest);
     for (auto& v : instances) tr.common_scalar(v);
     pc.mark("witness+upload");
     // ---- P2: advice commitments.  The random polynomial of P7 depends on no challenge: its
     // coefficients (blinding stream position known up front) and its commitment ride in the same launch.
     const uint64_t ctr_rand = (uint64_t)A * nb + A + (uint64_t)L * (2 * nb + 2) + (uint64_t)(S + L) * (bf + 1);
-    if (in.draws) {
-        pr->h_rand.reserve((size_t)n * sizeof(Fr));
-        memcpy(pr->h_rand.p, in.draws + ctr_rand, (size_t)n * sizeof(Fr));
-        SHP_HIP(hipMemcpyAsync(pr->rand_poly, pr->h_rand.p, (size_t)n * sizeof(Fr), hipMemcpyHostToDevice, st));
-    } else {
-        ChaKey ck;
-        memcpy(ck.w, key, 32);
-        hipLaunchKernelGGL(chacha_fr_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, ck, ctr_rand, n, pr->rand_poly);
+    {
+        // witness rows, instances and the random polynomial reach the device in one dispatch (ingest_kernel)
+        IngestArgs ia;
+        ia.grid = grid; ia.vals = V(0); ia.inst = V(I_INST); ia.rand_poly = pr->rand_poly; ia.h_rand = nullptr;
+        ia.n = n; ia.n_adv = A; ia.rows_now = rows_now; ia.u = u; ia.n_inst = (uint32_t)instances.size();
+        memcpy(ia.key.w, key, 32);
+        ia.counter0 = ctr_rand;
+        if (in.draws) {
+            pr->h_rand.reserve((size_t)n * sizeof(Fr));
+            memcpy(pr->h_rand.p, in.draws + ctr_rand, (size_t)n * sizeof(Fr));
+            ia.h_rand = pr->h_rand.as<Fr>();
+        }
+        hipLaunchKernelGGL(ingest_kernel, dim3(ceil_div(n, 256), A + 2), dim3(256), 0, st, ia);
     }
     std::vector<G1Affine> pts(std::max<uint32_t>({A + 1, 2 * L, S + L + 1, P.degree}));
     const MsmRows adv_rows{rows_now, u, n - u};       // assigned rows + blinding rows; the rest is zero

@@ -196,6 +196,43 @@ __global__ void chacha_fr_kernel(ChaKey key8, uint64_t counter0, uint32_t count,
     st(out + i, fr_draw(key, counter0 + i));
 }
 
+// Everything a proof brings to the device, in ONE dispatch: the kernel reads the lane's pinned witness grid itself
+// (three copies and a kernel before; a dispatch costs a busy stream tens of microseconds whatever its size).
+//   blockIdx.y <  n_adv   advice column y: rows [0, rows_now) and the blinding rows [u, n)
+//   blockIdx.y == n_adv   the instance column (n_inst values; the rows behind them stay zero)
+//   blockIdx.y == n_adv+1 the n coefficients of the random polynomial: ChaCha20 draws, or the caller's (h_rand)
+struct IngestArgs {
+    const Fr* grid;          // pinned host memory, [n_adv + 1][n]
+    Fr* vals;                // device, advice columns [n_adv][n]
+    Fr* inst;                // device instance column
+    Fr* rand_poly;
+    const Fr* h_rand;        // pinned host memory or null
+    uint32_t n, n_adv, rows_now, u, n_inst;
+    ChaKey key;
+    uint64_t counter0;
+};
+__global__ void ingest_kernel(IngestArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (y < a.n_adv) {
+        const uint32_t moved = a.rows_now + (a.n - a.u);
+        if (i >= moved) return;
+        const uint32_t r = i < a.rows_now ? i : a.u + (i - a.rows_now);
+        st(a.vals + (size_t)y * a.n + r, ld(a.grid + (size_t)y * a.n + r));
+    } else if (y == a.n_adv) {
+        if (i < a.n_inst) st(a.inst + i, ld(a.grid + (size_t)a.n_adv * a.n + i));
+    } else {
+        if (i >= a.n) return;
+        if (a.h_rand) {
+            st(a.rand_poly + i, ld(a.h_rand + i));
+        } else {
+            uint32_t key[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) key[j] = a.key.w[j];
+            st(a.rand_poly + i, fr_draw(key, a.counter0 + i));
+        }
+    }
+}
+
 // ------------------------------------------------------------------ grand products
 constexpr int MAX_PERM_COLS = 64;
 struct PermArgs {
