@@ -660,6 +660,7 @@ struct shp_prover {
     Fr *sc_tot = nullptr;                                      // [6][SC][nb]: tot_a, tot_b, bpre_a, bsuf_b | [SC] inv
     uint32_t sc_cnt = 0;
     uint32_t* sc_done = nullptr;                               // [SC] workgroups of a product scan that have stored their totals
+    uint32_t* lk_done = nullptr;                               // [L] flag workgroups of a lookup that have finished
     std::vector<void*> owned;
     template <class T>
     T* dalloc(size_t count) {
@@ -751,6 +752,8 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->sc_tot = pr->dalloc<Fr>((size_t)5 * pr->sc_cnt * SCAN_THREADS);
     pr->sc_done = pr->dalloc<uint32_t>(pr->sc_cnt);            // zero between launches: the last workgroup resets its counter
     SHP_HIP(hipMemset(pr->sc_done, 0, pr->sc_cnt * sizeof(uint32_t)));
+    pr->lk_done = pr->dalloc<uint32_t>(std::max<size_t>(P.lookups.size(), 1));
+    SHP_HIP(hipMemset(pr->lk_done, 0, std::max<size_t>(P.lookups.size(), 1) * sizeof(uint32_t)));
     pr->msm_ws.timers = &pr->timers;
     pr->wscratch.assign(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
     {
@@ -1088,10 +1091,11 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         for (uint32_t l = 0; l < L; l++) herr[l] = 0;
         uint32_t nt = std::min<uint32_t>(1024, n);
         // sorted input of lookup l at sort_out[2l], sorted table at sort_out[2l+1]
-        hipLaunchKernelGGL(lookup_flags_kernel, dim3(ceil_div(u, 256), L), dim3(256), 0, st, pr->sort_out, pr->sort_out + n,
-                           (size_t)2 * n, u, n, pr->rank);
-        hipLaunchKernelGGL(lookup_permute_kernel, dim3(L), dim3(nt), 0, st, pr->sort_out, pr->sort_out + n, (size_t)2 * n, u, n,
-                           V(I_PIN), V(I_PIN + 1), (size_t)2 * n, pr->rep_scratch, pr->rank, lk_blinds, herr);
+        LookupPermuteArgs lp;
+        lp.pin_all = V(I_PIN); lp.ptab_all = V(I_PIN + 1); lp.pstride = (size_t)2 * n; lp.scratch_all = pr->rep_scratch;
+        lp.blinds = lk_blinds; lp.err = herr; lp.done = pr->lk_done;
+        hipLaunchKernelGGL(lookup_flags_kernel, dim3(ceil_div(u, nt), L), dim3(nt), 0, st, pr->sort_out, pr->sort_out + n,
+                           (size_t)2 * n, u, n, pr->rank, lp);
         commit(srs->msm_gl, V(I_PIN), 2 * L, pts.data());                 // the MSM run synchronises the stream
         for (uint32_t l = 0; l < L; l++)
             SHP_REQUIRE(herr[l] == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");

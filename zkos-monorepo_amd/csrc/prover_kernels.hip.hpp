@@ -632,37 +632,23 @@ __device__ __forceinline__ uint32_t block_scan_u32_excl(uint32_t v, uint32_t* sh
     return r;
 }
 
-// flags of the sorted input a / sorted table tb (raw), one lane per usable row, whole chip:
-//   bit 0  a[i] is the first of its run          bit 1  that first occurrence is missing from the table
-//   bit 2  tb[i] stays in the leftover list (it is not the first of a run that the input also holds)
-__global__ __launch_bounds__(256) void lookup_flags_kernel(const Fr* a_all, const Fr* tb_all, size_t sstride, uint32_t u,
-                                                           uint32_t n, uint32_t* flags_all) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
-    if (i >= u) return;
-    const Fr* a = a_all + (size_t)l * sstride;
-    const Fr* tb = tb_all + (size_t)l * sstride;
-    const Fr ai = ld(a + i), ti = ld(tb + i);
-    uint32_t f = 0;
-    const bool first = i == 0 || raw_cmp(ld(a + i - 1), ai) != 0;
-    if (first) {
-        f |= 1u;
-        if (!bsearch_raw(tb, u, ai)) f |= 2u;
-    }
-    const bool tfirst = i == 0 || raw_cmp(ld(tb + i - 1), ti) != 0;
-    if (!(tfirst && bsearch_raw(a, u, ti))) f |= 4u;
-    flags_all[(size_t)l * n + i] = f;
-}
-
 // a = sorted input (raw), tb = sorted table (raw); writes permuted input / table (Montgomery)
 // rows [0,u) and the blinding rows [u,n) of both; err[l] != 0 when the input of lookup l is not in the table (one plain
 // store per workgroup: `err` and `blinds` may live in pinned host memory, read and written over the host link).
-// One workgroup per lookup: only prefix sums over the flags and the scatter are left here.
-__global__ __launch_bounds__(1024) void lookup_permute_kernel(const Fr* a_all, const Fr* tb_all, size_t sstride, uint32_t u,
-                                                              uint32_t n, Fr* pin_all, Fr* ptab_all, size_t pstride,
-                                                              uint32_t* scratch_all, const uint32_t* flags_all, const Fr* blinds,
-                                                              uint32_t* err) {
-    __shared__ uint32_t sh[1024];
-    const uint32_t l = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+// One workgroup per lookup (the last one of lookup_flags_kernel): only prefix sums over the flags and the scatter are left here.
+struct LookupPermuteArgs {
+    Fr *pin_all, *ptab_all;
+    size_t pstride;
+    uint32_t* scratch_all;
+    const Fr* blinds;
+    uint32_t* err;
+    uint32_t* done;          // per lookup: flag workgroups finished (zero between launches)
+};
+__device__ __forceinline__ void lookup_permute_body(const Fr* a_all, const Fr* tb_all, size_t sstride, uint32_t u, uint32_t n,
+                                                    Fr* pin_all, Fr* ptab_all, size_t pstride, uint32_t* scratch_all,
+                                                    const uint32_t* flags_all, const Fr* blinds, uint32_t* err, uint32_t l,
+                                                    uint32_t* sh /* [1024] */) {
+    const uint32_t t = threadIdx.x, nt = blockDim.x;
     const Fr* a = a_all + (size_t)l * sstride;
     const Fr* tb = tb_all + (size_t)l * sstride;
     Fr* pin = pin_all + (size_t)l * pstride;
@@ -706,6 +692,42 @@ __global__ __launch_bounds__(1024) void lookup_permute_kernel(const Fr* a_all, c
         st(pin + u + t, ld(blinds + (size_t)(2 * l) * nb + t));
         st(ptab + u + t, ld(blinds + (size_t)(2 * l + 1) * nb + t));
     }
+}
+
+// flags of the sorted input a / sorted table tb (raw), one lane per usable row, whole chip:
+//   bit 0  a[i] is the first of its run          bit 1  that first occurrence is missing from the table
+//   bit 2  tb[i] stays in the leftover list (it is not the first of a run that the input also holds)
+// grid (ceil(u / blockDim), L), blockDim = min(1024, n).  The workgroup that finishes a lookup's flags last goes on with
+// its permutation (lookup_permute_body: prefix sums over the flags and the scatter, one workgroup's work) -- no second
+// dispatch; device-scope fences on both sides of the count, as the flags come from workgroups on other XCDs.
+__global__ __launch_bounds__(1024) void lookup_flags_kernel(const Fr* a_all, const Fr* tb_all, size_t sstride, uint32_t u,
+                                                            uint32_t n, uint32_t* flags_all, LookupPermuteArgs pa) {
+    __shared__ uint32_t sh[1024];
+    __shared__ uint32_t is_last;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (i < u) {
+        const Fr* a = a_all + (size_t)l * sstride;
+        const Fr* tb = tb_all + (size_t)l * sstride;
+        const Fr ai = ld(a + i), ti = ld(tb + i);
+        uint32_t f = 0;
+        const bool first = i == 0 || raw_cmp(ld(a + i - 1), ai) != 0;
+        if (first) {
+            f |= 1u;
+            if (!bsearch_raw(tb, u, ai)) f |= 2u;
+        }
+        const bool tfirst = i == 0 || raw_cmp(ld(tb + i - 1), ti) != 0;
+        if (!(tfirst && bsearch_raw(a, u, ti))) f |= 4u;
+        flags_all[(size_t)l * n + i] = f;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(pa.done + l, 1u) + 1 == gridDim.x;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) pa.done[l] = 0;
+    lookup_permute_body(a_all, tb_all, sstride, u, n, pa.pin_all, pa.ptab_all, pa.pstride, pa.scratch_all, flags_all, pa.blinds,
+                        pa.err, l, sh);
 }
 
 // ------------------------------------------------------------------ quotient terms (extended domain)
