@@ -742,7 +742,38 @@ struct PermQArgs {
     Fr* h;
 };
 
-__global__ __launch_bounds__(256, 2) void perm_quotient_kernel(PermQArgs a) {
+struct LookupQArgs {
+    const Fr* z; const Fr* pin; const Fr* ptab;       // cosets
+    const Fr* ain; const Fr* stab;                     // theta-compressed input / table on the coset
+    const Fr* l0; const Fr* l_last; const Fr* l_active;
+    uint32_t mask;                                     // n - 1 (coset-major quotient domain)
+    Fr y, beta, gamma;
+    Fr* h;
+};
+
+// the five lookup terms folded into h at row i
+__device__ __forceinline__ Fr lookup_quotient_terms(Fr h, const LookupQArgs& a, uint32_t i) {
+    const Fr l0 = ld(a.l0 + i), ll = ld(a.l_last + i), la = ld(a.l_active + i);
+    const Fr z = ld(a.z + i), ap = ld(a.pin + i), sp = ld(a.ptab + i);
+    const uint32_t base = i & ~a.mask, inext = base | ((i + 1) & a.mask), iprev = base | ((i - 1) & a.mask);
+    h = h * a.y + l0 * (Fr::one() - z);
+    h = h * a.y + ll * (Fr::sqr(z) - z);
+    Fr lhs = ld(a.z + inext) * (ap + a.beta) * (sp + a.gamma);
+    Fr rhs = z * (ld(a.ain + i) + a.beta) * (ld(a.stab + i) + a.gamma);
+    h = h * a.y + la * (lhs - rhs);
+    Fr d = ap - sp;
+    h = h * a.y + l0 * d;
+    h = h * a.y + la * d * (ap - ld(a.pin + iprev));
+    return h;
+}
+
+__global__ void lookup_quotient_kernel(LookupQArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    st(a.h + i, lookup_quotient_terms(ld(a.h + i), a, i));
+}
+
+// with_lookup: the terms of the first lookup follow in the same pass (h stays in registers, one dispatch fewer)
+__global__ __launch_bounds__(256, 2) void perm_quotient_kernel(PermQArgs a, LookupQArgs lq, uint32_t with_lookup) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t ne = a.stride;
     const uint32_t base = i & ~a.mask;
@@ -767,32 +798,7 @@ __global__ __launch_bounds__(256, 2) void perm_quotient_kernel(PermQArgs a) {
         }
         h = h * a.y + la * (left - right);
     }
-    st(a.h + i, h);
-}
-
-struct LookupQArgs {
-    const Fr* z; const Fr* pin; const Fr* ptab;       // cosets
-    const Fr* ain; const Fr* stab;                     // theta-compressed input / table on the coset
-    const Fr* l0; const Fr* l_last; const Fr* l_active;
-    uint32_t mask;                                     // n - 1 (coset-major quotient domain)
-    Fr y, beta, gamma;
-    Fr* h;
-};
-
-__global__ void lookup_quotient_kernel(LookupQArgs a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    Fr h = ld(a.h + i);
-    const Fr l0 = ld(a.l0 + i), ll = ld(a.l_last + i), la = ld(a.l_active + i);
-    const Fr z = ld(a.z + i), ap = ld(a.pin + i), sp = ld(a.ptab + i);
-    const uint32_t base = i & ~a.mask, inext = base | ((i + 1) & a.mask), iprev = base | ((i - 1) & a.mask);
-    h = h * a.y + l0 * (Fr::one() - z);
-    h = h * a.y + ll * (Fr::sqr(z) - z);
-    Fr lhs = ld(a.z + inext) * (ap + a.beta) * (sp + a.gamma);
-    Fr rhs = z * (ld(a.ain + i) + a.beta) * (ld(a.stab + i) + a.gamma);
-    h = h * a.y + la * (lhs - rhs);
-    Fr d = ap - sp;
-    h = h * a.y + l0 * d;
-    h = h * a.y + la * d * (ap - ld(a.pin + iprev));
+    if (with_lookup) h = lookup_quotient_terms(h, lq, i);
     st(a.h + i, h);
 }
 
