@@ -65,17 +65,87 @@ def program_hash(slots, prog, adv_q, fix_q, inst_q):
     return h
 
 
+def selector_runs(prog, fix_q):
+    """Gates that are `selector * expression` with the SAME selector query in consecutive OUT instructions:
+    acc = (..((acc y + s g1) y + s g2)..) y + s gk  ==  acc y^k + s (g1 y^(k-1) + .. + gk)
+    -- k + 2 products instead of 2 k.  Returns {OUT index: (run id, position, run length, MUL index, expr slot, query)}
+    for every OUT that takes part in a run of at least two; exact field arithmetic, so the values are the same."""
+    last_write = {}
+    info = {}                                   # OUT index -> (mul index, expr slot, selector query) when the pattern holds
+    reads_after = {}
+    for i, (op, dst, a, b) in enumerate(prog):
+        if op == OP_OUT:
+            w = last_write.get(a)
+            if w is not None and prog[w][0] == OP_MUL:
+                _, _, ma, mb = prog[w]
+                for sel_slot, expr_slot in ((ma, mb), (mb, ma)):
+                    lw = max((j for j in range(w) if prog[j][1] == sel_slot and prog[j][0] != OP_OUT), default=None)
+                    if lw is not None and prog[lw][0] == OP_FIX and sel_slot != expr_slot:
+                        # the product must feed this OUT alone: no other read of its slot until the slot is rewritten
+                        other = False
+                        for j in range(w + 1, len(prog)):
+                            o, d, x, y = prog[j]
+                            rd = (x,) if o in (OP_NEG, OP_OUT) else (x, y) if o in (OP_ADD, OP_SUB, OP_MUL) else ()
+                            if j != i and a in rd:
+                                other = True
+                            if o != OP_OUT and d == a and j > i:
+                                break
+                        if not other:
+                            info[i] = (w, expr_slot, fix_q[prog[lw][2]])
+                        break
+        else:
+            last_write[dst] = i
+    outs = [i for i, ins in enumerate(prog) if ins[0] == OP_OUT]
+    runs, cur = [], []
+    for i in outs:
+        if i in info and cur and info[cur[-1]][2] == info[i][2]:
+            cur.append(i)
+        else:
+            if len(cur) >= 2:
+                runs.append(cur)
+            cur = [i] if i in info else []
+    if len(cur) >= 2:
+        runs.append(cur)
+    plan = {}
+    for rid, run in enumerate(runs):
+        for pos, i in enumerate(run):
+            plan[i] = (rid, pos, len(run)) + info[i]
+    return plan
+
+
 def emit_kernel(name, slots, prog, adv_q, fix_q, inst_q):
     def row(rot):
         if rot == 0:
             return "row"
         return "((row & a.hi_mask) | ((row + (uint32_t)(%d * (int32_t)a.rot_step)) & a.size_mask))" % rot
 
+    runs = selector_runs(prog, fix_q)
+    elided = {v[3]: i for i, v in runs.items()}                 # MUL index -> its OUT
+    lengths = sorted({v[2] for v in runs.values()})
     L = ["__global__ __launch_bounds__(PROG_THREADS) void %s(ProgArgs a) {" % name,
          "    const uint32_t row = blockIdx.x * PROG_THREADS + threadIdx.x;",
          "    Fr acc = a.acc_in ? ld(a.acc_in + row) : Fr::zero();",
          "    Fr " + ", ".join("s%d = Fr::zero()" % i for i in range(slots)) + ";"]
-    for op, dst, a, b in prog:
+    if runs:
+        L.append("    // runs of gates under one selector: acc y^k + selector * (g1 y^(k-1) + .. + gk), k + 2 products for 2 k")
+        L.append("    Fr inner = Fr::zero();")
+        # y^k by an addition chain written out here (Fr::pow_u64 walks a 256-bit exponent)
+        have = {1: "a.mult"}
+
+        def power(k):
+            if k in have:
+                return have[k]
+            h = power(k // 2)
+            L.append("    const Fr ysq%d = %s * %s;" % (k - k % 2, h, h))
+            have[k - k % 2] = "ysq%d" % (k - k % 2)
+            if k % 2:
+                L.append("    const Fr yod%d = ysq%d * a.mult;" % (k, k - 1))
+                have[k] = "yod%d" % k
+            return have[k]
+
+        for k in lengths:
+            L.append("    const Fr ypow%d = %s;" % (k, power(k)))
+    for i, (op, dst, a, b) in enumerate(prog):
         if op == OP_CONST:
             L.append("    s%d = ld(a.consts + %d);" % (dst, a))
         elif op == OP_ADV:
@@ -89,11 +159,20 @@ def emit_kernel(name, slots, prog, adv_q, fix_q, inst_q):
         elif op == OP_SUB:
             L.append("    s%d = s%d - s%d;" % (dst, a, b))
         elif op == OP_MUL:
-            L.append("    s%d = s%d * s%d;" % (dst, a, b))
+            if i in elided:
+                L.append("    const Fr gate%d = s%d;" % (elided[i], runs[elided[i]][4]))   # the selector is applied once per run
+            else:
+                L.append("    s%d = s%d * s%d;" % (dst, a, b))
         elif op == OP_NEG:
             L.append("    s%d = Fr::neg(s%d);" % (dst, a))
         elif op == OP_OUT:
-            L.append("    acc = acc * a.mult + s%d;" % a)
+            if i in runs:
+                rid, pos, length, w, expr_slot, (col, rot) = runs[i]
+                L.append(("    inner = gate%d;" if pos == 0 else "    inner = inner * a.mult + gate%d;") % i)
+                if pos == length - 1:
+                    L.append("    acc = acc * ypow%d + ld(a.fix_base + (size_t)%d * a.fix_stride + %s) * inner;" % (length, col, row(rot)))
+            else:
+                L.append("    acc = acc * a.mult + s%d;" % a)
         else:
             raise ValueError(op)
     L += ["    st(a.out + row, acc);", "}"]
