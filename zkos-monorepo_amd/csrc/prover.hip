@@ -1223,7 +1223,9 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     }
     const Fr* d_points = (const Fr*)staged(points.data(), points.size() * sizeof(Fr));
     {
-        uint32_t per = 1;                                   // one power per thread: the chain is the exponentiation alone
+        // a lone proof: one power per thread (the chain is the exponentiation alone, ~20 dependent products); a pool
+        // lane: 16 consecutive powers per thread (exponentiation + 16 products: 2.3 products per power instead of 20)
+        const uint32_t per = pr->throughput ? 16 : 1;
         const Fr xn = Fr::pow_u64(x, n);                    // the extra grid row combines the quotient pieces into hx
         hipLaunchKernelGGL(powers_kernel, dim3(ceil_div(ceil_div(n, per), 256), (uint32_t)points.size() + 1), dim3(256), 0, st,
                            d_points, (uint32_t)points.size(), n, per, pr->pw, (const Fr*)hp, npieces, xn, pr->hx);
