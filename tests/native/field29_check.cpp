@@ -111,6 +111,25 @@ int main(int argc, char** argv) {
         G1X29 got2 = g1_add29(got, a29);
         if (!same_point(to_g1x(got2), want2)) { printf("add29 (second level) mismatch: case %d kind %d\n", it, (int)kind); return 1; }
     }
+    // 4. the same arithmetic over Fr (the quotient kernels): products, squares, subtractions, both conversions
+    using LR = Lazy29<FrParams>;
+    constexpr l29::L9 RKP3 = LR::kp_spread(3), RKP40 = LR::kp_spread(40, 2);
+    for (int it = 0; it < rounds; it++) {
+        Fr lo, hi, lo2, hi2;
+        for (int i = 0; i < 8; i++) { lo.l[i] = (uint32_t)rnd(); hi.l[i] = (uint32_t)rnd(); lo2.l[i] = (uint32_t)rnd(); hi2.l[i] = (uint32_t)rnd(); }
+        const Fr a = Fr::from_u512(lo, hi), b = Fr::from_u512(lo2, hi2);
+        const LR::El a29 = LR::split<5>(a), b29 = LR::from_fp_reduced(b);          // < 32 p, < 1.1 p
+        if (LR::to_fp(LR::mul(a29, b29)) != a * b) { printf("Fr mul mismatch at %d\n", it); return 1; }
+        if (LR::to_fp(LR::sqr(b29)) != b * b) { printf("Fr sqr mismatch at %d\n", it); return 1; }
+        if (LR::to_fp(LR::sub(LR::from_fp_reduced(a), b29, RKP3)) != a - b) { printf("Fr sub mismatch at %d\n", it); return 1; }
+        // an un-normalised operand (three values added limb by limb) against a large multiple of p
+        LR::El s3;
+        for (int i = 0; i < 9; i++) s3.l[i] = a29.l[i] + b29.l[i] + b29.l[i];
+        if (LR::to_fp(LR::mul(s3, b29)) != (a + b + b) * b) { printf("Fr lazy-operand mul mismatch at %d\n", it); return 1; }
+        LR::El bb;
+        for (int i = 0; i < 9; i++) bb.l[i] = a29.l[i] + b29.l[i];                 // < 33.1 p, limbs < 2^30
+        if (LR::to_fp(LR::sub(b29, bb, RKP40)) != b - (a + b)) { printf("Fr wide sub mismatch at %d\n", it); return 1; }
+    }
     printf("ok %d products, %ld additions, %ld general additions\n", rounds, adds, gadds);
     return 0;
 }
