@@ -885,7 +885,9 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     auto PL = [&](uint32_t idx) { return pr->polys + (size_t)idx * n; };
     auto CS = [&](uint32_t idx) { return pr->cos + (size_t)idx * ne; };
     // product scans over `cnt` vectors of n elements (prover_kernels.hip.hpp "product scans")
-    const uint32_t sbs = std::min<uint32_t>(SCAN_THREADS, n), snb = n / sbs;
+    // elements per thread: a lone proof keeps the chains short, pool lanes (the GPU is full anyway) save two thirds of the products
+    const uint32_t sce = pr->throughput ? SCAN_E_POOL : 1;
+    const uint32_t sbs = std::min<uint32_t>(SCAN_THREADS, n / sce), snb = n / (sbs * sce);
     Fr* const sc_ta = pr->sc_tot;
     Fr* const sc_tb = pr->sc_tot + (size_t)pr->sc_cnt * SCAN_THREADS;
     Fr* const sc_bpre = pr->sc_tot + (size_t)2 * pr->sc_cnt * SCAN_THREADS;
@@ -903,7 +905,8 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         ScanTotals T;
         T.bpre_a = sc_bpre; T.bsuf_b = sc_bsuf; T.inv_b = sc_inv; T.total_out = totals; T.done = pr->sc_done;
         T.omegas = diff_points ? pk->omegas : nullptr; T.points = diff_points;
-        hipLaunchKernelGGL(scan_local_kernel, dim3(snb, cnt), dim3(sbs), 0, st, a, b, n, pr->sc_pre, pr->sc_suf, sc_ta, sc_tb, T);
+        hipLaunchKernelGGL(sce == 1 ? scan_local_kernel<1> : scan_local_kernel<SCAN_E_POOL>, dim3(snb, cnt), dim3(sbs), 0, st, a, b,
+                           n, pr->sc_pre, pr->sc_suf, sc_ta, sc_tb, T);
         if (on_host) {
             sync_stream(st);
             il.n = cnt;
@@ -915,7 +918,8 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     auto invert_point_diffs = [&](const Fr* points, Fr* out, uint32_t cnt) {
         pr->timers.begin(KID_BATCH_INVERT, st);
         const InvList il = product_scans(nullptr, nullptr, cnt, points);
-        hipLaunchKernelGGL(batch_invert_apply_kernel, dim3(snb, cnt), dim3(sbs), 0, st, pr->sc_pre, pr->sc_suf, sc_bpre, sc_bsuf,
+        hipLaunchKernelGGL(sce == 1 ? batch_invert_apply_kernel<1> : batch_invert_apply_kernel<SCAN_E_POOL>, dim3(snb, cnt),
+                           dim3(sbs), 0, st, (const Fr*)nullptr, pk->omegas, points, pr->sc_pre, pr->sc_suf, sc_bpre, sc_bsuf,
                            sc_inv, n, out, il);
         pr->timers.end(st);
     };
@@ -1129,8 +1133,9 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     pr->timers.begin(KID_GRAND_PRODUCT, st);
     if (S + L) {                                           // a plan may have neither a permutation nor a lookup
         const InvList il = product_scans(pr->num, pr->den, S + L);
-        hipLaunchKernelGGL(grand_product_apply_kernel, dim3(snb, S + L), dim3(sbs), 0, st, pr->sc_pre, pr->sc_suf, sc_bpre,
-                           sc_bsuf, sc_inv, n, S, u, bf, V(I_PZ), (size_t)n, z_blinds, il);
+        hipLaunchKernelGGL(sce == 1 ? grand_product_apply_kernel<1> : grand_product_apply_kernel<SCAN_E_POOL>, dim3(snb, S + L),
+                           dim3(sbs), 0, st, pr->num, pr->den, pr->sc_pre, pr->sc_suf, sc_bpre, sc_bsuf, sc_inv, n, S, u, bf,
+                           V(I_PZ), (size_t)n, z_blinds, il);
     }
     pr->timers.end(st);
     SHP_REQUIRE(ctr == ctr_rand, SHP_ERR_INTERNAL, "prove: blinding stream position of the random polynomial");

@@ -310,13 +310,17 @@ __device__ __forceinline__ Fr block_scan_bwd_excl(Fr v, Fr* sh, uint32_t t, uint
 }
 
 // ------------------------------------------------------------------ product scans over many workgroups
-// Prefix products of `a` and suffix products of `b` over `cnt` products of `n` elements each, in
-// two short launches instead of one long single-workgroup chain:
-//   scan_local   every min(256, n)-element block: exclusive prefix of a, inclusive suffix of b, block totals; the
-//                workgroup that stores a product's last totals goes on with scan_totals_body: exclusive prefix /
-//                suffix of the block totals and the ONE inversion of the product of all b (Kaliski, Fp::inv)
-//   apply        element-wise (grand_product_apply / batch_invert_apply)
+// Prefix products of `a` and suffix products of `b` over `cnt` products of `n` elements each, in two launches.  Every
+// thread owns E CONSECUTIVE elements: their product is a serial chain (one product per element), only the per-thread
+// products go through the wave-wide scan (twelve products per thread), and the apply kernels walk the thread's elements
+// again -- about 7 products per element for E = 8 where one element per thread pays 18.  E = 1 keeps the shortest
+// dependency chain and is what a lone proof uses; pool lanes, which fill the GPU between them, use E = 8.
+//   scan_local   per thread: exclusive prefix of a and exclusive suffix of b over the threads of its workgroup, and the
+//                workgroup's totals; the workgroup that stores a product's last totals goes on with scan_totals_body:
+//                exclusive prefix / suffix of the block totals and the ONE inversion of the product of all b (Kaliski)
+//   apply        grand_product_apply / batch_invert_apply
 constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_E_POOL = 8;
 
 __device__ __forceinline__ Fr shfl_up_fr(const Fr& v, int d) {
     Fr r;
@@ -337,8 +341,6 @@ __device__ __forceinline__ Fr shfl_fr(const Fr& v, int src) {
     return r;
 }
 
-// grid (n / bs, cnt), bs = blockDim.x = min(256, n).
-// pre_a[i] = prod_{block start <= r < i} a_r ; suf_b[i] = prod_{i <= r < block end} b_r
 __device__ __forceinline__ void scan_totals_body(const Fr* tot_a, const Fr* tot_b, uint32_t nb, Fr* bpre_a, Fr* bsuf_b, Fr* inv_b,
                                                  Fr* total_out, uint32_t p, Fr* sh);
 struct ScanTotals {          // what the last workgroup of a product does with the block totals (scan_totals_body)
@@ -348,39 +350,55 @@ struct ScanTotals {          // what the last workgroup of a product does with t
     // here instead of being read from a and b
     const Fr *omegas, *points;
 };
+// grid (n / (bs E), cnt), bs = blockDim.x = min(256, n / E).  Thread `slot` of product p owns elements [slot E, slot E + E):
+// pre_a[p][slot] = product of a over the workgroup's elements before them, suf_b[p][slot] = product of b over the
+// workgroup's elements after them
+template <int E>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_local_kernel(const Fr* a, const Fr* b, uint32_t n, Fr* pre_a, Fr* suf_b,
                                                                   Fr* tot_a, Fr* tot_b, ScanTotals T) {
     __shared__ Fr wa[SCAN_THREADS / 64], wb[SCAN_THREADS / 64];
     __shared__ Fr sh_tot[SCAN_THREADS];
     __shared__ uint32_t is_last;
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, bs = blockDim.x, nw = bs >> 6;
-    const size_t i = (size_t)blockIdx.y * n + (size_t)blockIdx.x * bs + t;
-    Fr va, vb;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, bs = blockDim.x, nw = (bs + 63) >> 6;
+    const uint32_t wl = bs < 64 ? bs : 64;                 // lanes of a wave that hold a thread
+    const uint32_t slot = blockIdx.x * bs + t;
+    Fr ia, sb;                             // the thread's own products, then inclusive prefix / suffix inside the wave
     if (T.omegas) {
-        va = ld(T.omegas + (size_t)blockIdx.x * bs + t) - ld(T.points + blockIdx.y);
-        vb = va;
+        const Fr pt = ld(T.points + blockIdx.y);
+        const Fr* om = T.omegas + (size_t)slot * E;
+        ia = ld(om) - pt;
+#pragma unroll
+        for (int j = 1; j < E; j++) ia = ia * (ld(om + j) - pt);
+        sb = ia;
     } else {
-        va = ld(a + i);
-        vb = ld(b + i);
+        const size_t e0 = (size_t)blockIdx.y * n + (size_t)slot * E;
+        ia = ld(a + e0);
+        sb = ld(b + e0);
+#pragma unroll
+        for (int j = 1; j < E; j++) {
+            ia = ia * ld(a + e0 + j);
+            sb = sb * ld(b + e0 + j);
+        }
     }
-    Fr ia = va, sb = vb;                   // inclusive prefix of a / inclusive suffix of b inside the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         Fr ua = shfl_up_fr(ia, off), db = shfl_down_fr(sb, off);
         if ((int)lane >= off) ia = ia * ua;
-        if ((int)lane + off < 64) sb = sb * db;
+        if (lane + off < wl) sb = sb * db;
     }
-    if (lane == 63) wa[wave] = ia;
+    if (lane == wl - 1) wa[wave] = ia;
     if (lane == 0) wb[wave] = sb;
     __syncthreads();
-    Fr ea = shfl_up_fr(ia, 1);             // exclusive prefix inside the wave
+    Fr ea = shfl_up_fr(ia, 1), sx = shfl_down_fr(sb, 1);   // exclusive inside the wave
     if (lane == 0) ea = Fr::one();
+    if (lane == wl - 1) sx = Fr::one();
     for (uint32_t w = 0; w < wave; w++) ea = ea * wa[w];
-    for (uint32_t w = wave + 1; w < nw; w++) sb = sb * wb[w];
-    st(pre_a + i, ea);
-    st(suf_b + i, sb);
+    for (uint32_t w = wave + 1; w < nw; w++) sx = sx * wb[w];
+    const size_t th = (size_t)blockIdx.y * (n / E) + slot;
+    st(pre_a + th, ea);
+    st(suf_b + th, sx);
     if (t == 0) {
-        const uint32_t nb = n / bs;
+        const uint32_t nb = gridDim.x;
         Fr ta = wa[0], tb = wb[0];
         for (uint32_t w = 1; w < nw; w++) { ta = ta * wa[w]; tb = tb * wb[w]; }
         st(tot_a + (size_t)blockIdx.y * nb + blockIdx.x, ta);
@@ -394,10 +412,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_local_kernel(const Fr* a, c
     if (!is_last) return;
     __threadfence();
     if (t == 0) T.done[blockIdx.y] = 0;
-    scan_totals_body(tot_a, tot_b, n / bs, T.bpre_a, T.bsuf_b, T.inv_b, T.total_out, blockIdx.y, sh_tot);
+    scan_totals_body(tot_a, tot_b, gridDim.x, T.bpre_a, T.bsuf_b, T.inv_b, T.total_out, blockIdx.y, sh_tot);
 }
 
-// One workgroup of 256 threads (or one wave when nb <= 64) for product p, nb = n / 256 <= 256 block totals per product.
+// The threads of one workgroup (256, or fewer when the product has one block) for product p, nb <= 256 block totals.
 // bpre_a[k] = prod_{j<k} tot_a[j]; bsuf_b[k] = prod_{j>k} tot_b[j]; inv_b = 1 / prod_j tot_b[j]
 // total_out (pinned host memory) non-null: the product of all b goes there instead of its inverse into inv_b --
 // a lone proof inverts it on the host (3 us + a stream round trip) rather than on one GPU lane (55 us)
@@ -407,6 +425,7 @@ __device__ __forceinline__ void scan_totals_body(const Fr* tot_a, const Fr* tot_
     if (nb <= 64) {
         // the usual case (n <= 2^14): one wave, both scans by shuffles in one pass, no barriers
         if (t >= 64) return;
+        const uint32_t wl = blockDim.x < 64 ? blockDim.x : 64;   // nb <= wl: a product with several blocks has full ones
         const Fr xa = t < nb ? ld(tot_a + (size_t)p * nb + t) : Fr::one();
         const Fr xb = t < nb ? ld(tot_b + (size_t)p * nb + t) : Fr::one();
         Fr ia = xa, sb = xb;
@@ -414,11 +433,11 @@ __device__ __forceinline__ void scan_totals_body(const Fr* tot_a, const Fr* tot_
         for (int off = 1; off < 64; off <<= 1) {
             Fr ua = shfl_up_fr(ia, off), db = shfl_down_fr(sb, off);
             if ((int)t >= off) ia = ia * ua;
-            if ((int)t + off < 64) sb = sb * db;
+            if (t + off < wl) sb = sb * db;
         }
         Fr ea = shfl_up_fr(ia, 1), eb = shfl_down_fr(sb, 1);
         if (t == 0) ea = Fr::one();
-        if (t == 63) eb = Fr::one();
+        if (t == wl - 1) eb = Fr::one();
         if (t < nb) {
             st(bpre_a + (size_t)p * nb + t, ea);
             st(bsuf_b + (size_t)p * nb + t, eb);
@@ -452,40 +471,84 @@ struct InvList {
 
 // z[p][i] = c_p * prod_{r<i} num_r / prod_{r<i} den_r for i <= usable, blinding rows after it.
 // Products [0, n_sets) are the chained permutation sets (c_p = prod_{j<p} z_j[usable]); the rest
-// (lookups) start at 1.  grid (n / 256, cnt).
-__global__ __launch_bounds__(SCAN_THREADS) void grand_product_apply_kernel(const Fr* pre_num, const Fr* suf_den, const Fr* bpre,
-                                                                          const Fr* bsuf, const Fr* inv_den, uint32_t n,
-                                                                          uint32_t n_sets, uint32_t usable, uint32_t bf, Fr* zbase,
-                                                                          size_t zstride, const Fr* blinds, InvList il) {
-    const uint32_t p = blockIdx.y, bs = blockDim.x, nb = n / bs;
-    const uint32_t i = blockIdx.x * bs + threadIdx.x;
+// (lookups) start at 1.  Launched like scan_local_kernel<E>, whose outputs pre_num / suf_den / bpre / bsuf are.
+// 1 / prod_{r<i} den_r is formed as (prod_{r>=i} den_r) / (prod of all den): no element is inverted.
+template <int E>
+__global__ __launch_bounds__(SCAN_THREADS) void grand_product_apply_kernel(const Fr* num, const Fr* den, const Fr* pre_num,
+                                                                          const Fr* suf_den, const Fr* bpre, const Fr* bsuf,
+                                                                          const Fr* inv_den, uint32_t n, uint32_t n_sets,
+                                                                          uint32_t usable, uint32_t bf, Fr* zbase, size_t zstride,
+                                                                          const Fr* blinds, InvList il) {
+    __shared__ Fr chain;                   // c_p / (product of all den_p)
+    const uint32_t p = blockIdx.y, bs = blockDim.x, tpp = n / E, nb = gridDim.x;
+    auto inv_of = [&](uint32_t q) { return il.n ? il.v[q] : ld(inv_den + q); };
+    if (threadIdx.x == 0) {
+        Fr c = inv_of(p);
+        if (p < n_sets) {
+            const uint32_t su = usable / E, ju = usable % E, ku = su / bs;
+            for (uint32_t q = 0; q < p; q++) {             // z_q[usable] from the chunk that holds row `usable`
+                const size_t thq = (size_t)q * tpp + su, eq = (size_t)q * n + (size_t)su * E;
+                Fr up = ld(pre_num + thq) * ld(bpre + (size_t)q * nb + ku);
+                for (uint32_t j = 0; j < ju; j++) up = up * ld(num + eq + j);
+                Fr dn = ld(suf_den + thq) * ld(bsuf + (size_t)q * nb + ku);
+                for (uint32_t j = ju; j < (uint32_t)E; j++) dn = dn * ld(den + eq + j);
+                c = c * (up * dn * inv_of(q));
+            }
+        }
+        chain = c;
+    }
+    __syncthreads();
+    const uint32_t slot = blockIdx.x * bs + threadIdx.x, i0 = slot * E;
     Fr* z = zbase + (size_t)p * zstride;
-    if (i > usable) {
-        st(z + i, ld(blinds + (size_t)p * bf + (i - usable - 1)));
+    const Fr* bl = blinds + (size_t)p * bf;
+    if (i0 > usable) {
+#pragma unroll
+        for (int j = 0; j < E; j++) st(z + i0 + j, ld(bl + (i0 + j - usable - 1)));
         return;
     }
-    auto zhat = [&](uint32_t q, uint32_t r) {
-        const size_t e = (size_t)q * n + r;
-        const size_t k = (size_t)q * nb + r / bs;
-        return ld(pre_num + e) * ld(bpre + k) * (ld(suf_den + e) * ld(bsuf + k)) * (il.n ? il.v[q] : ld(inv_den + q));
-    };
-    Fr v = zhat(p, i);
-    if (p < n_sets)
-        for (uint32_t q = 0; q < p; q++) v = v * zhat(q, usable);
-    st(z + i, v);
+    const size_t th = (size_t)p * tpp + slot, k = (size_t)p * nb + blockIdx.x, e0 = (size_t)p * n + i0;
+    Fr sf[E];                              // sf[j] = product of den from element j of the chunk to the end of the vector
+    sf[E - 1] = ld(den + e0 + E - 1) * (ld(suf_den + th) * ld(bsuf + k));
+#pragma unroll
+    for (int j = E - 2; j >= 0; j--) sf[j] = ld(den + e0 + j) * sf[j + 1];
+    Fr pf = ld(pre_num + th) * ld(bpre + k) * chain;
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const uint32_t i = i0 + j;
+        st(z + i, i > usable ? ld(bl + (i - usable - 1)) : pf * sf[j]);
+        if (j + 1 < E) pf = pf * ld(num + e0 + j);
+    }
 }
 
-// out[p][i] = 1 / in[p][i] from the scans of `in` against itself
-__global__ __launch_bounds__(SCAN_THREADS) void batch_invert_apply_kernel(const Fr* pre, const Fr* suf, const Fr* bpre, const Fr* bsuf,
-                                                                         const Fr* inv_tot, uint32_t n, Fr* out, InvList il) {
-    const uint32_t p = blockIdx.y, bs = blockDim.x, nb = n / bs, t = threadIdx.x, lane = t & 63;
-    const size_t e = (size_t)p * n + (size_t)blockIdx.x * bs + t;
-    const size_t k = (size_t)p * nb + blockIdx.x;
-    // exclusive suffix inside the block = inclusive suffix of the next element (1 at the block end)
-    Fr sn = ld(suf + e);
-    Fr se = shfl_down_fr(sn, 1);
-    if (lane == 63) se = t + 1 < bs ? ld(suf + e + 1) : Fr::one();
-    st(out + e, ld(pre + e) * ld(bpre + k) * (se * ld(bsuf + k)) * (il.n ? il.v[p] : ld(inv_tot + p)));
+// out[p][i] = 1 / v[p][i] from the scans of v against itself; v = in, or omega^r - points[p] when omegas is non-null
+// (as in scan_local_kernel).  Launched like scan_local_kernel<E>.
+template <int E>
+__global__ __launch_bounds__(SCAN_THREADS) void batch_invert_apply_kernel(const Fr* in, const Fr* omegas, const Fr* points,
+                                                                         const Fr* pre, const Fr* suf, const Fr* bpre,
+                                                                         const Fr* bsuf, const Fr* inv_tot, uint32_t n, Fr* out,
+                                                                         InvList il) {
+    const uint32_t p = blockIdx.y, bs = blockDim.x, nb = gridDim.x;
+    const uint32_t slot = blockIdx.x * bs + threadIdx.x;
+    const size_t th = (size_t)p * (n / E) + slot, k = (size_t)p * nb + blockIdx.x, e0 = (size_t)p * n + (size_t)slot * E;
+    Fr v[E];
+    if (omegas) {
+        const Fr pt = ld(points + p);
+#pragma unroll
+        for (int j = 0; j < E; j++) v[j] = ld(omegas + (size_t)slot * E + j) - pt;
+    } else {
+#pragma unroll
+        for (int j = 0; j < E; j++) v[j] = ld(in + e0 + j);
+    }
+    Fr sf[E];                              // product of every element after element j of the chunk
+    sf[E - 1] = ld(suf + th) * ld(bsuf + k);
+#pragma unroll
+    for (int j = E - 2; j >= 0; j--) sf[j] = sf[j + 1] * v[j + 1];
+    Fr pf = ld(pre + th) * ld(bpre + k) * (il.n ? il.v[p] : ld(inv_tot + p));   // (product of every element before) / total
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        st(out + e0 + j, pf * sf[j]);
+        if (j + 1 < E) pf = pf * v[j];
+    }
 }
 
 // ------------------------------------------------------------------ lookup permutation
