@@ -237,10 +237,15 @@ int32_t shp_pk_save(const shp_pk* pk, uint8_t* out, size_t out_cap, size_t* out_
 int32_t shp_pk_load(shp_ctx* ctx, shp_srs* srs, const uint8_t* bytes, size_t len, shp_pk** out);
 int32_t shp_pk_info(const shp_pk* pk, uint32_t* k, uint32_t* n_witness_inputs, uint32_t* n_instances,
                     uint32_t* proof_len);
-/* *compiled = 1 when the key's gate expressions run as a kernel compiled ahead of time -- the library is built with
- * straight-line code for the gate programs of the circuit plans it ships, as the reference builds its circuits in at
- * build time (/root/reference/crates/shielder_bindings/build.rs:19-48) -- and 0 when they are interpreted (any other
- * plan, or SHP_GATE_AOT=0 in the environment at keygen).  Proof bytes do not depend on it. */
+/* How the key evaluates the quotient's expressions.  The library is built with straight-line code for the circuit
+ * plans it ships, as the reference builds its circuits in at build time
+ * (/root/reference/crates/shielder_bindings/build.rs:19-48):
+ *   *compiled = 2  the whole numerator of the quotient (gate program, permutation and lookup terms) is one compiled
+ *                  kernel in 29-bit lazy arithmetic;
+ *   *compiled = 1  the gate program is a compiled kernel, the other terms run in the generic kernels (a plan with a
+ *                  shipped gate program but another permutation / lookup structure, or SHP_QUOT29=0 at keygen);
+ *   *compiled = 0  everything is interpreted (any other plan, or SHP_GATE_AOT=0 in the environment at keygen).
+ * Proof bytes do not depend on it. */
 int32_t shp_pk_gate_compiled(const shp_pk* pk, int32_t* compiled);
 /* verifying-key material: transcript digest, fixed and permutation commitments (64 B affine each) */
 int32_t shp_pk_vk_digest(const shp_pk* pk, uint8_t out[32]);

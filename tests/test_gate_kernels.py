@@ -1,6 +1,8 @@
-"""The gate kernels compiled ahead of time for the shipped circuit plans (tools/gen_gate_kernels.py ->
-zkos-monorepo_amd/csrc/gate_kernels.inc): the committed file is what the plans generate, a key over a shipped plan uses
-its compiled kernel, and compiled and interpreted gate programs give the same proof bytes -- the oracle's."""
+"""The kernels compiled ahead of time for the shipped circuit plans -- gate programs (tools/gen_gate_kernels.py ->
+zkos-monorepo_amd/csrc/gate_kernels.inc) and whole quotient numerators in 29-bit lazy arithmetic
+(tools/gen_quotient_kernels.py -> csrc/quotient_kernels.inc): the committed files are what the plans generate, a key
+over a shipped plan uses its compiled kernels, and every level (compiled quotient, compiled gates, interpreted) gives the
+same proof bytes -- the oracle's."""
 import importlib
 import os
 import random
@@ -16,6 +18,19 @@ TAU = 0x1234567890ABCDEF1234567890ABCDEF55
 def test_committed_gate_kernels_are_what_the_plans_generate():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_gate_kernels.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_committed_quotient_kernels_are_what_the_plans_generate():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_quotient_kernels.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_quotient_kernel_bounds_hold_on_concrete_integers():
+    """the generator's static bounds of the lazy 29-bit arithmetic, checked by running the emitted operation sequence on
+    integers: no 64-bit column sum or 32-bit limb overflows, no subtraction goes negative, the result is the plain
+    modular one"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_quotient_kernels.py"), "--selfcheck"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.count("bounds hold") >= 2, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
@@ -34,19 +49,24 @@ def test_compiled_and_interpreted_gate_programs_give_the_oracle_proof(shp, oracl
         seed = bytes([7]) * 32
         want = PL.prove(opk, osrs, wit, seed)
         monkeypatch.delenv("SHP_GATE_AOT", raising=False)
+        monkeypatch.delenv("SHP_QUOT29", raising=False)
+        pk_q = shp.ProvingKey(gpu_ctx, params, plan_bytes)
+        assert pk_q.compiled_level() == 2, "the withdraw-shaped plan is shipped with a compiled quotient kernel"
+        monkeypatch.setenv("SHP_QUOT29", "0")
         pk_c = shp.ProvingKey(gpu_ctx, params, plan_bytes)
-        assert pk_c.gate_compiled(), "the withdraw-shaped plan is shipped with a compiled gate kernel"
+        assert pk_c.gate_compiled() and pk_c.compiled_level() == 1, "the withdraw-shaped plan is shipped with a compiled gate kernel"
+        monkeypatch.delenv("SHP_QUOT29", raising=False)
         monkeypatch.setenv("SHP_GATE_AOT", "0")
         pk_i = shp.ProvingKey(gpu_ctx, params, plan_bytes)
         assert not pk_i.gate_compiled()
         monkeypatch.delenv("SHP_GATE_AOT", raising=False)
-        for pk in (pk_c, pk_i):
+        for pk in (pk_q, pk_c, pk_i):
             for mode in (False, True):                     # latency and throughput lanes pick different interpreters
                 pr = shp.Prover(pk)
                 pr.mode(mode)
                 assert pr.prove(wit, seed) == want
                 pr.close()
-        pk_c.close(); pk_i.close(); params.close()
+        pk_q.close(); pk_c.close(); pk_i.close(); params.close()
 
 
 @pytest.mark.gpu

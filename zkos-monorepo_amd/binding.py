@@ -429,6 +429,13 @@ class ProvingKey:
         _check(lib().shp_pk_gate_compiled(self.h, C.byref(v)))
         return bool(v.value)
 
+    def compiled_level(self) -> int:
+        """0: the quotient's expressions are interpreted; 1: the gate program runs as a compiled kernel; 2: the whole
+        numerator of the quotient (gates, permutation and lookup terms) runs as one compiled kernel"""
+        v = C.c_int32(0)
+        _check(lib().shp_pk_gate_compiled(self.h, C.byref(v)))
+        return v.value
+
     def vk_digest(self) -> bytes:
         out = C.create_string_buffer(32)
         _check(lib().shp_pk_vk_digest(self.h, out))

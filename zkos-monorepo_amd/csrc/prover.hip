@@ -20,6 +20,7 @@
 #include <thread>
 
 #include "prover_kernels.hip.hpp"
+#include "quotient29.hip.hpp"
 #include "poseidon2.hip.hpp"
 #include "verify.hpp"
 
@@ -91,6 +92,11 @@ struct shp_pk {
     Fr *x_ext = nullptr, *omegas = nullptr, *consts = nullptr;
     Instr* gate_prog = nullptr;
     void (*gate_fn)(ProgArgs) = nullptr;           // the compiled gate program, when the plan is one the library ships
+    // the compiled quotient kernel (gates, permutation and lookup terms in one pass, 29-bit lazy arithmetic), when the
+    // plan is one the library ships.  Non-null: twist, x_ext, consts29 and with them fixed_cos, sigma_cos, l0, l_last,
+    // l_active are in Montgomery radix 2^261 (quotient29.hip.hpp) and the quotient phase runs this kernel alone
+    void (*quot_fn)(Quot29Args) = nullptr;
+    Fr* consts29 = nullptr;
     std::vector<Instr*> lk_in_prog, lk_tab_prog;
     Query *adv_q = nullptr, *fix_q = nullptr, *inst_q = nullptr;
     // host copies
@@ -158,6 +164,47 @@ static GateKernelFn find_gate_kernel(const PlanData& P) {
     return nullptr;
 }
 
+// The whole numerator of the quotient as one generated kernel per shipped plan (tools/gen_quotient_kernels.py); the
+// kernels are compiled in quotient.hip.
+// FNV-1a over what the generated quotient kernel depends on: the gate program and query lists, the constraint degree
+// (it sets the size of a permutation set), the permutation columns, every lookup's compression programs
+static uint64_t quotient_hash(const PlanData& P) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    auto eat = [&](uint32_t w) {
+        for (int i = 0; i < 4; i++) {
+            h = (h ^ ((w >> (8 * i)) & 0xffu)) * 0x100000001B3ull;
+        }
+    };
+    auto eat_prog = [&](uint32_t slots, const std::vector<Instr>& prog) {
+        eat(slots);
+        eat((uint32_t)prog.size());
+        for (const Instr& in : prog) { eat(in.op); eat(in.dst); eat(in.a); eat(in.b); }
+    };
+    eat_prog(P.gate_slots, P.gate_prog);
+    for (const std::vector<Query>* qs : {&P.adv_q, &P.fix_q, &P.inst_q}) {
+        eat((uint32_t)qs->size());
+        for (const Query& q : *qs) { eat(q.col); eat((uint32_t)q.rot); }
+    }
+    eat(P.degree);
+    eat((uint32_t)P.perm_cols.size());
+    for (const auto& c : P.perm_cols) { eat(c.first); eat(c.second); }
+    eat((uint32_t)P.lookups.size());
+    for (const LookupPlan& lk : P.lookups) {
+        eat(lk.m);
+        eat_prog(lk.in_slots, lk.in_prog);
+        eat_prog(lk.tab_slots, lk.tab_prog);
+    }
+    return h;
+}
+
+static QuotientKernelFn find_quotient_kernel(const PlanData& P) {
+    for (const char* name : {"SHP_GATE_AOT", "SHP_QUOT29"}) {       // A/B and tests: the separate radix-2^256 kernels
+        const char* e = getenv(name);
+        if (e && e[0] == '0') return nullptr;
+    }
+    return quotient_kernel_for(quotient_hash(P));
+}
+
 // `b` non-null: a second program of the same size in the same launch
 static void launch_prog(hipStream_t st, const ProgArgs& a, uint32_t size, bool throughput, const ProgArgs* b = nullptr) {
     // up to 16 slots: the register-file interpreter (no LDS) for throughput lanes -- it leaves the CU's LDS to the
@@ -214,6 +261,10 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     pk->nc = nc;
     pk->nq = nq;
     // omega^i; the quotient domain's points c_j omega^t, twists c_j^i and untwists c_j^-t
+    pk->quot_fn = find_quotient_kernel(P);
+    // a key with a generated quotient kernel keeps what that kernel reads in Montgomery radix 2^261: a factor 32 on the
+    // twists (every coset transform of this key passes it on to its output) and on the points of the quotient domain
+    const Fr radix_shift = pk->quot_fn ? Fr::from_u64(32) : Fr::one();
     std::vector<Fr> om(n), xe(nq), tw(nq), ci(nq), cj(nc);
     {
         Fr a = Fr::one();
@@ -222,9 +273,9 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
         for (uint32_t j = 0; j < nc; j++) { cj[j] = a; a = a * om_ext; }
         for (uint32_t j = 0; j < nc; j++) {
             const Fr cinv1 = Fr::inv(cj[j]);
-            Fr p = Fr::one(), q = Fr::one();
+            Fr p = radix_shift, q = Fr::one();
             for (uint32_t t = 0; t < n; t++) {
-                xe[(size_t)j * n + t] = cj[j] * om[t];
+                xe[(size_t)j * n + t] = cj[j] * om[t] * radix_shift;
                 tw[(size_t)j * n + t] = p;
                 ci[(size_t)j * n + t] = q;
                 p = p * cj[j];
@@ -323,6 +374,11 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
         pk->vinv = pk->dupload(I);                 // h_m = sum_j vinv[m][j] * y_j / (c_j^n - 1)
     }
     pk->consts = pk->dupload(P.consts);
+    if (pk->quot_fn) {
+        std::vector<Fr> c29(P.consts);
+        for (Fr& c : c29) c = c * radix_shift;
+        pk->consts29 = pk->dupload(c29);
+    }
     pk->gate_prog = pk->dupload(P.gate_prog);
     pk->gate_fn = find_gate_kernel(P);
     for (auto& lk : P.lookups) {
@@ -1156,6 +1212,22 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     ntt_launch(ctx, pr->polys, pr->cos, k, (NV + 1) * pk->nc, ext, st, pr->ntt_tmp);
     // ---- P10: quotient
     const uint32_t ebs = std::min<uint32_t>(256, n);      // element-wise kernels over the quotient domain (n >= 64)
+    if (pk->quot_fn) {
+        // one generated kernel for the whole numerator; the challenges go in in its radix (2^261)
+        const Fr c32 = Fr::from_u64(32);
+        Quot29Args qa;
+        qa.cos = pr->cos; qa.ne = ne;
+        qa.fixed_cos = pk->fixed_cos; qa.sigma_cos = pk->sigma_cos;
+        qa.l0 = pk->l0; qa.l_last = pk->l_last; qa.l_active = pk->l_active; qa.x_ext = pk->x_ext;
+        qa.consts = pk->consts29;
+        qa.i_pin = I_PIN; qa.i_pz = I_PZ; qa.i_lz = I_LZ; qa.i_inst = I_INST;
+        qa.mask = n - 1; qa.rot_last = P.rot_last;
+        qa.y = y * c32; qa.theta = theta * c32; qa.beta = beta * c32; qa.gamma = gamma * c32; qa.delta = pk->delta * c32;
+        qa.h = pr->h;
+        pr->timers.begin(KID_PROG, st);
+        hipLaunchKernelGGL(pk->quot_fn, dim3(ne / QUOT29_THREADS), dim3(QUOT29_THREADS), 0, st, qa);
+        pr->timers.end(st);
+    } else {
     extended_domain(pa);
     pa.mult = y; pa.acc_in = nullptr;
     pa.prog = pk->gate_prog; pa.n_instr = (uint32_t)P.gate_prog.size(); pa.nslots = P.gate_slots;
@@ -1202,6 +1274,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     for (uint32_t l = l_first; l < L; l++) {
         const LookupQArgs q = lookup_args(l);
         hipLaunchKernelGGL(lookup_quotient_kernel, dim3(ne / ebs), dim3(ebs), 0, st, q);
+    }
     }
     // per-coset interpolants, then the nc x nc solve per coefficient: the quotient pieces [nc][n] (in the buffer
     // the lookup compression no longer needs)
@@ -1582,7 +1655,7 @@ int32_t shp_pk_info(const shp_pk* pk, uint32_t* k, uint32_t* n_witness_inputs, u
 int32_t shp_pk_gate_compiled(const shp_pk* pk, int32_t* compiled) {
     return guarded([&] {
         SHP_REQUIRE(pk && compiled, SHP_ERR_INVALID_ARG, "pk_gate_compiled: null argument");
-        *compiled = pk->gate_fn ? 1 : 0;
+        *compiled = pk->quot_fn ? 2 : pk->gate_fn ? 1 : 0;
     });
 }
 
