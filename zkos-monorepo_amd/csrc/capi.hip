@@ -117,10 +117,9 @@ static void srs_finish(shp_srs* s) {
         }
         keccak256(m.data(), m.size(), s->fingerprint);
     }
-    int32_t rc = shp_msm_create_dev(s->ctx, s->d_g, s->n, 0, &s->msm_g);
-    SHP_REQUIRE(rc == SHP_OK, rc, std::string("srs: msm plan over g: ") + shp_last_error());
-    rc = shp_msm_create_dev(s->ctx, s->d_gl, s->n, 0, &s->msm_gl);
-    SHP_REQUIRE(rc == SHP_OK, rc, std::string("srs: msm plan over g_lagrange: ") + shp_last_error());
+    // the Lagrange basis first: it carries most of a proof's commitments and gets the larger share of the HBM
+    msm_create_for_srs(s->ctx, s->d_gl, s->n, true, &s->msm_gl);
+    msm_create_for_srs(s->ctx, s->d_g, s->n, false, &s->msm_g);
 }
 
 static void srs_release(shp_srs* s) {

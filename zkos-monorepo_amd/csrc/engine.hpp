@@ -129,6 +129,10 @@ struct MsmJob {
 };
 }  // namespace shp
 void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& ws, hipStream_t st);
+namespace shp {
+// the MSM plan of one of an SRS's two bases: the primary one (built first) may take the larger multiples table
+void msm_create_for_srs(shp_ctx* ctx, const void* d_bases, size_t n, bool primary, shp_msm** out);
+}  // namespace shp
 
 namespace shp {
 // A proving pool's lanes reach their commitment phases at different times; each phase alone is a launch of a few

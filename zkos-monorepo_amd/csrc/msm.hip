@@ -547,7 +547,8 @@ __global__ __launch_bounds__(64) void msm_multiples_kernel(const G1Affine* __res
 }
 
 // One launch serves any number of jobs (segments): `batch` MSMs each, over its own multiples table and scalar
-// columns, all tables of one shape (n, c, W).  The segment table lives in device memory; workgroup -> segment by
+// columns; the tables hold the same number of bases but may differ in window width (the two bases of an SRS do).
+// The segment table lives in device memory; workgroup -> segment by
 // binary search over wg_base (a by-value array indexed dynamically would be copied to scratch).
 struct DirectSeg {
     const G1Affine* mult;
@@ -560,13 +561,15 @@ struct DirectSeg {
     uint32_t wg_base;     // first blockIdx.x of the segment
     uint32_t msm_base;    // index of its first MSM in the launch
     uint64_t part_base;   // its partials: [batch][gy][gx] from here
+    // its table: window width, windows, entries per (window, base), windows per lane in this launch (a window group
+    // beyond the table's last window adds nothing), the bias that makes the digits signed
+    uint32_t c, W, NB, T;
+    Fr bias;
 };
 struct DirectArgs {
     const DirectSeg* segs;
     uint32_t n_segs;
     size_t n_table;
-    uint32_t c, W, NB, T;
-    Fr bias;
     G1X* partials;
     uint32_t* done;       // per MSM of the launch: workgroups that have stored their partial sum
     G1X* out;             // per MSM: the sum (may be pinned host memory)
@@ -889,33 +892,33 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
     const size_t part = sg.part_base + ((size_t)m * gridDim.y + blockIdx.y) * sg.gx + blk;
     const size_t i = lane < sg.prefix ? lane : (size_t)sg.tail_start + (lane - sg.prefix);
     const G1Affine* __restrict__ mult = sg.mult;
-    const uint32_t w0 = blockIdx.y * a.T;
-    const uint32_t w1 = w0 + a.T < a.W ? w0 + a.T : a.W;
+    const uint32_t w0 = blockIdx.y * sg.T;
+    const uint32_t w1 = w0 + sg.T < sg.W ? w0 + sg.T : sg.W;
     G1X acc = G1X::inf();
     G1X29 acc29;
     acc29.inf = true;
-    if (lane < visited) {
+    if (lane < visited && w0 < sg.W) {
         Fr raw = load_fr(sg.scalars + (size_t)m * sg.stride + i).to_raw();
         if (!raw.is_zero()) {
             uint64_t cy = 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                cy += (uint64_t)raw.l[j] + a.bias.l[j];
+                cy += (uint64_t)raw.l[j] + sg.bias.l[j];
                 raw.l[j] = (uint32_t)cy;
                 cy >>= 32;
             }
-            const uint32_t half = a.NB;
+            const uint32_t half = sg.NB;
             // next non-zero digit at or after window w: (table slot, sign), slot == NB means none
-            raw_shr_any(raw, w0 * a.c);                // the group's first window at bit 0
+            raw_shr_any(raw, w0 * sg.c);               // the group's first window at bit 0
             auto next_digit = [&](uint32_t& w, uint32_t& neg) -> size_t {
                 for (; w < w1; w++) {
-                    uint32_t d = raw_pop_bits(raw, a.c);
+                    uint32_t d = raw_pop_bits(raw, sg.c);
                     neg = 0;
-                    if (w + 1 < a.W) {
+                    if (w + 1 < sg.W) {
                         neg = d < half;
                         d = neg ? half - d : d - half;
                     }
-                    if (d) return ((size_t)w * a.n_table + i) * a.NB + (d - 1);
+                    if (d) return ((size_t)w * a.n_table + i) * sg.NB + (d - 1);
                 }
                 return (size_t)-1;
             };
@@ -981,16 +984,23 @@ static uint32_t pick_window(size_t n) {
     return (uint32_t)c;
 }
 
-// direct-table budget per plan (GiB); SHP_MSM_TABLE_GB=0 forces the bucket method
-static double direct_budget_gib() {
+// Direct-table budget per plan (GiB); SHP_MSM_TABLE_GB=0 forces the bucket method.
+// An SRS holds two bases.  The Lagrange basis carries two thirds of a proof's commitments (advice, permuted lookup
+// columns, grand products, the SHPLONK quotients), so it is the PRIMARY table: built first, it may take c = 15 (k = 13:
+// 146 GB, 17 windows).  The coefficient basis (random polynomial, quotient pieces) and every stand-alone plan stop at
+// c = 14 (82 GB, 19 windows; c = 13: 43 GB, 20 windows, -1.5 % proofs/s; c = 12: -5 %).
+enum class TableRole { Single, Primary, Secondary };
+
+static double direct_budget_gib(TableRole role) {
     const char* e = getenv("SHP_MSM_TABLE_GB");
     if (e && *e) return atof(e);
-    return 84.0;       // k = 13: c = 14, 82 GB per basis, 19 windows (c = 13: 43 GB, 20 windows, -1.5 % proofs/s; c = 12: -5 %)
+    return role == TableRole::Primary ? 140.0 : 84.0;
 }
 
+// scalars are canonical (< r < 2^254)
 static uint32_t direct_windows(uint32_t c) {
-    uint32_t W = (255 + c - 1) / c;
-    if (255 - (int)(c * (W - 1)) > (int)c - 1) W++;       // the unsigned top digit must be <= 2^(c-1)
+    uint32_t W = (254 + c - 1) / c;
+    if (254 - (int)(c * (W - 1)) > (int)c - 1) W++;       // the unsigned top digit (plus a carry) must be <= 2^(c-1)
     return W;
 }
 
@@ -1012,13 +1022,16 @@ static double hbm_available(shp_ctx* ctx) {
     return avail;
 }
 
-// largest c in [8, below] whose full multiples table fits both the per-table budget and the device: a table may take half
-// of what is free after 6 GiB of headroom (build scratch, proving workspaces), the other half being left for the sibling
-// basis that every SRS builds next.  0 = none fits: use buckets.
-static uint32_t pick_direct_window(shp_ctx* ctx, size_t n, uint32_t below = 15) {
+// largest c in [8, below) whose full multiples table fits both the per-table budget and the device, after 6 GiB of
+// headroom (build scratch, proving workspaces).  A stand-alone plan may take half of what is free; of an SRS's two
+// tables the primary one 55 % (the sibling follows) and the secondary one 85 % of what is then left.  0 = none fits: use
+// buckets.
+static uint32_t pick_direct_window(shp_ctx* ctx, size_t n, TableRole role, uint32_t below) {
     const double gib = 1073741824.0;
-    const double budget = std::min(direct_budget_gib() * gib, (hbm_available(ctx) - 6.0 * gib) / 2.0);
-    for (uint32_t c = std::min<uint32_t>(14, below - 1); c >= 8; c--)
+    const double share = role == TableRole::Primary ? 0.55 : role == TableRole::Secondary ? 0.85 : 0.5;
+    const double budget = std::min(direct_budget_gib(role) * gib, (hbm_available(ctx) - 6.0 * gib) * share);
+    const uint32_t cmax = role == TableRole::Primary ? 15 : 14;
+    for (uint32_t c = std::min<uint32_t>(cmax, below - 1); c >= 8; c--)
         if (direct_table_bytes(n, c) <= budget) return c;
     return 0;
 }
@@ -1055,14 +1068,15 @@ static void msm_build_direct(shp_ctx* ctx, shp_msm* m, const G1Affine* d_bases) 
     }
 }
 
-static void msm_build(shp_ctx* ctx, const G1Affine* d_bases, size_t n, uint32_t window_bits, shp_msm** out) {
+static void msm_build(shp_ctx* ctx, const G1Affine* d_bases, size_t n, uint32_t window_bits, shp_msm** out,
+                      TableRole role = TableRole::Single) {
     SHP_REQUIRE(ctx && out && n > 0, SHP_ERR_INVALID_ARG, "msm_create: bad arguments");
     std::unique_ptr<shp_msm> m(new shp_msm);
     m->ctx = ctx;
     m->n = n;
     // window_bits == 0: direct multiples table when it fits the HBM budget, buckets otherwise;
     // an explicit window_bits always selects the bucket method with that window
-    uint32_t cd = window_bits ? 0 : pick_direct_window(ctx, n);
+    uint32_t cd = window_bits ? 0 : pick_direct_window(ctx, n, role, 16);
     while (cd) {
         m->direct = true;
         m->c = cd;
@@ -1080,7 +1094,7 @@ static void msm_build(shp_ctx* ctx, const G1Affine* d_bases, size_t n, uint32_t 
             if (m->d_table) { (void)hipFree(m->d_table); m->d_table = nullptr; }
             if (m->d_mult) { (void)hipFree(m->d_mult); m->d_mult = nullptr; }
             m->direct = false;
-            cd = pick_direct_window(ctx, n, cd);
+            cd = pick_direct_window(ctx, n, role, cd);
         }
     }
     uint32_t c = window_bits ? window_bits : pick_window(n);
@@ -1122,13 +1136,15 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
     SHP_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= shp::MSM_MAX_JOBS, SHP_ERR_INVALID_ARG, "msm: bad job list");
     const shp_msm* m0 = jobs[0].m;
     SHP_REQUIRE(m0 && m0->direct, SHP_ERR_INVALID_ARG, "msm: job list needs direct-table plans");
-    const uint32_t W = m0->W;
+    uint32_t W = 0;                                            // the most windows any of the tables has
+    for (uint32_t k = 0; k < n_jobs; k++)
+        if (jobs[k].m) W = std::max(W, jobs[k].m->W);
     std::vector<DirectSeg> segs(n_jobs);
     uint64_t busy_wgs = 0, total = 0, visited_all = 0;
     for (uint32_t k = 0; k < n_jobs; k++) {
         const shp::MsmJob& jb = jobs[k];
-        SHP_REQUIRE(jb.m && jb.m->direct && jb.m->n == m0->n && jb.m->c == m0->c && jb.m->W == W, SHP_ERR_INVALID_ARG,
-                    "msm: the jobs of one launch need plans of the same shape");
+        SHP_REQUIRE(jb.m && jb.m->direct && jb.m->n == m0->n, SHP_ERR_INVALID_ARG,
+                    "msm: the jobs of one launch need direct-table plans over the same number of bases");
         SHP_REQUIRE(jb.scalars && jb.h_out && jb.batch, SHP_ERR_INVALID_ARG, "msm: bad job");
         SHP_REQUIRE(jb.rows.prefix <= jb.m->n && (size_t)jb.rows.tail_start + jb.rows.tail_count <= jb.m->n &&
                         (jb.rows.tail_count == 0 || jb.rows.prefix <= jb.rows.tail_start),
@@ -1137,6 +1153,7 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
         DirectSeg& sg = segs[k];
         sg.mult = jb.m->d_mult; sg.scalars = jb.scalars; sg.stride = jb.stride;
         sg.prefix = jb.rows.prefix; sg.tail_start = jb.rows.tail_start; sg.tail_count = jb.rows.tail_count;
+        sg.c = jb.m->c; sg.W = jb.m->W; sg.NB = jb.m->NB; sg.bias = jb.m->bias; sg.T = 0;
         sg.gx = ceil_div(std::max<uint32_t>(visited, 1), MSM_THREADS);
         sg.wg_base = (uint32_t)busy_wgs;
         sg.msm_base = (uint32_t)total;
@@ -1158,6 +1175,7 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
     const uint32_t gy = ceil_div(W, T);
     uint64_t parts = 0;
     for (uint32_t k = 0; k < n_jobs; k++) {
+        segs[k].T = ceil_div(segs[k].W, gy);                  // a table's windows spread over the launch's groups
         segs[k].part_base = parts;
         parts += (uint64_t)jobs[k].batch * segs[k].gx * gy;
     }
@@ -1196,7 +1214,7 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
     DirectArgs a;
     a.segs = ws.segs.as<DirectSeg>() + seg_at; a.n_segs = n_jobs;
     a.n_table = m0->n;
-    a.c = m0->c; a.W = W; a.NB = m0->NB; a.T = T; a.bias = m0->bias; a.partials = ws.pf.as<G1X>();
+    a.partials = ws.pf.as<G1X>();
     a.done = ws.done.as<uint32_t>();
     a.out = ws.h_out.as<G1X>();                                // straight into pinned host memory: no copy dispatch
     KernelTimers none, *tm = ws.timers ? ws.timers : &none;
@@ -1434,6 +1452,10 @@ void msm_run(shp_msm* m, const Fr* d_scalars, size_t n_scalars, size_t stride, u
     SHP_REQUIRE(m, SHP_ERR_INVALID_ARG, "msm: null plan");
     std::lock_guard<std::mutex> g(m->mu);
     msm_run_ws(m, m->ws, d_scalars, n_scalars, stride, batch, h_out, st);
+}
+
+void shp::msm_create_for_srs(shp_ctx* ctx, const void* d_bases, size_t n, bool primary, shp_msm** out) {
+    msm_build(ctx, (const G1Affine*)d_bases, n, 0, out, primary ? TableRole::Primary : TableRole::Secondary);
 }
 
 extern "C" {
