@@ -520,7 +520,7 @@ def kernel_text(name, pl):
     em = Emitter()
     emit_quotient(em, pl)
     head = ["__global__ __launch_bounds__(QUOT29_THREADS) void %s(Quot29Args a) {" % name,
-            "    const uint32_t i = blockIdx.x * QUOT29_THREADS + threadIdx.x;",
+            "    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;",
             "    const uint32_t base = i & ~a.mask;",
             "    const uint32_t inext = base | ((i + 1) & a.mask), iprev = base | ((i - 1) & a.mask);",
             "    const uint32_t ilast = base | ((i + (uint32_t)a.rot_last) & a.mask);",

@@ -1225,7 +1225,10 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         qa.y = y * c32; qa.theta = theta * c32; qa.beta = beta * c32; qa.gamma = gamma * c32; qa.delta = pk->delta * c32;
         qa.h = pr->h;
         pr->timers.begin(KID_PROG, st);
-        hipLaunchKernelGGL(pk->quot_fn, dim3(ne / QUOT29_THREADS), dim3(QUOT29_THREADS), 0, st, qa);
+        // a lone proof's 896 waves would leave every SIMD with at most one wave, issuing every other slot: half-filled
+        // waves (32 points each) put two on a SIMD and finish sooner; pool lanes keep full waves (half the instructions)
+        const uint32_t qbs = pr->throughput ? QUOT29_THREADS : QUOT29_THREADS / 2;
+        hipLaunchKernelGGL(pk->quot_fn, dim3(ne / qbs), dim3(qbs), 0, st, qa);
         pr->timers.end(st);
     } else {
     extended_domain(pa);

@@ -15,7 +15,7 @@ namespace shp {
 
 using R29 = Lazy29<FrParams>;
 using E29 = R29::El;
-constexpr int QUOT29_THREADS = 64;
+constexpr int QUOT29_THREADS = 64;     // most threads of a workgroup (one point of the quotient domain each)
 
 struct Quot29Args {
     const Fr* cos;                 // [columns][ne]: coset values of the proof's columns (advice first), radix 2^261
