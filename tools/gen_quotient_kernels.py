@@ -457,7 +457,7 @@ def emit_quotient(em, pl):
     if n_sets:
         em.barrier()
         em.lines.append("    // ---- permutation argument: %d columns in %d sets" % (len(perm), n_sets))
-        beta, gamma, delta = em.arg("a.beta", "a.beta"), em.arg("a.gamma", "a.gamma"), em.arg("a.delta", "a.delta")
+        gamma = em.arg("a.gamma", "a.gamma")
 
         def pz(s, row):
             return em.load("a.cos + (size_t)(a.i_pz + %d) * a.ne + %s" % (s, row))
@@ -467,11 +467,15 @@ def emit_quotient(em, pl):
         h = em.fold(h, y, em.mul(ll(), em.sub(em.mul(zl, zl), zl)))
         for s in range(1, n_sets):
             h = em.fold(h, y, em.mul(l0(), em.sub(pz(s, "i"), pz(s - 1, "ilast"))))
-        cur = em.mul(beta, em.load("a.x_ext + i"))                    # beta delta^c x, column after column
+        # beta sigma + v + gamma = beta (sigma + t) and beta delta^c x + v + gamma = beta (delta^c x + t) with
+        # t = (v + gamma) / beta: three products per column instead of four (delta^c x is a table of the key), and
+        # beta^(columns of the set) once per set
+        binv = em.arg("a.beta_inv", "a.beta_inv")
         for s in range(n_sets):
             em.barrier()
             left, right = pz(s, "inext"), pz(s, "i")
-            for c in range(s * chunk, min(len(perm), (s + 1) * chunk)):
+            cols = range(s * chunk, min(len(perm), (s + 1) * chunk))
+            for c in cols:
                 t, ix = perm[c]
                 if t == COL_ADVICE:
                     v = em.load("a.cos + (size_t)%d * a.ne + i" % ix)
@@ -479,12 +483,11 @@ def emit_quotient(em, pl):
                     v = em.load("a.fixed_cos + (size_t)%d * a.ne + i" % ix)
                 else:
                     v = em.load("a.cos + (size_t)a.i_inst * a.ne + i")
-                sig = em.load("a.sigma_cos + (size_t)%d * a.ne + i" % c)
-                left = em.mul(left, em.add(em.add(em.mul(beta, sig), v), gamma))
-                right = em.mul(right, em.add(em.add(cur, v), gamma))
-                if c + 1 < len(perm):
-                    cur = em.mul(cur, delta)
-            h = em.fold(h, y, em.mul(la(), em.sub(left, right)))
+                tq = em.mul(em.add(v, gamma), binv)
+                left = em.mul(left, em.add(em.load("a.sigma_cos + (size_t)%d * a.ne + i" % c), tq))
+                right = em.mul(right, em.add(em.load("a.dx_ext + (size_t)%d * a.ne + i" % c), tq))
+            bpow = em.arg("a.beta_pow_full", "a.beta_pow_full") if len(cols) == chunk else em.arg("a.beta_pow_last", "a.beta_pow_last")
+            h = em.fold(h, y, em.mul(em.mul(la(), em.sub(left, right)), bpow))
     for l, (m, s_in, p_in, s_tab, p_tab) in enumerate(pl["lookups"]):
         em.barrier()
         theta = lambda: em.arg("a.theta", "a.theta")

@@ -97,6 +97,7 @@ struct shp_pk {
     // l_active are in Montgomery radix 2^261 (quotient29.hip.hpp) and the quotient phase runs this kernel alone
     void (*quot_fn)(Quot29Args) = nullptr;
     Fr* consts29 = nullptr;
+    Fr* dx_ext = nullptr;                          // [PC][nq] delta^c x over the quotient domain (radix 2^261)
     std::vector<Instr*> lk_in_prog, lk_tab_prog;
     Query *adv_q = nullptr, *fix_q = nullptr, *inst_q = nullptr;
     // host copies
@@ -378,6 +379,10 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
         std::vector<Fr> c29(P.consts);
         for (Fr& c : c29) c = c * radix_shift;
         pk->consts29 = pk->dupload(c29);
+        std::vector<Fr> dx((size_t)PC * nq);
+        for (uint32_t c = 0; c < PC; c++)
+            for (uint32_t i = 0; i < nq; i++) dx[(size_t)c * nq + i] = pk->delta_pow[c] * xe[i];     // xe carries the 32
+        pk->dx_ext = pk->dupload(dx);
     }
     pk->gate_prog = pk->dupload(P.gate_prog);
     pk->gate_fn = find_gate_kernel(P);
@@ -1218,11 +1223,16 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         Quot29Args qa;
         qa.cos = pr->cos; qa.ne = ne;
         qa.fixed_cos = pk->fixed_cos; qa.sigma_cos = pk->sigma_cos;
-        qa.l0 = pk->l0; qa.l_last = pk->l_last; qa.l_active = pk->l_active; qa.x_ext = pk->x_ext;
+        qa.l0 = pk->l0; qa.l_last = pk->l_last; qa.l_active = pk->l_active; qa.dx_ext = pk->dx_ext;
         qa.consts = pk->consts29;
         qa.i_pin = I_PIN; qa.i_pz = I_PZ; qa.i_lz = I_LZ; qa.i_inst = I_INST;
         qa.mask = n - 1; qa.rot_last = P.rot_last;
-        qa.y = y * c32; qa.theta = theta * c32; qa.beta = beta * c32; qa.gamma = gamma * c32; qa.delta = pk->delta * c32;
+        qa.y = y * c32; qa.theta = theta * c32; qa.beta = beta * c32; qa.gamma = gamma * c32;
+        const uint32_t last_cols = PC - (S ? (S - 1) * P.chunk : 0);
+        SHP_REQUIRE(!beta.is_zero(), SHP_ERR_INTERNAL, "prove: the challenge beta is zero");     // probability 2^-254
+        qa.beta_inv = Fr::inv(beta) * c32;
+        qa.beta_pow_full = Fr::pow_u64(beta, P.chunk) * c32;
+        qa.beta_pow_last = Fr::pow_u64(beta, last_cols) * c32;
         qa.h = pr->h;
         pr->timers.begin(KID_PROG, st);
         // a lone proof's 896 waves would leave every SIMD with at most one wave, issuing every other slot: half-filled

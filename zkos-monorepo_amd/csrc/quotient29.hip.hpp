@@ -20,12 +20,14 @@ constexpr int QUOT29_THREADS = 64;     // most threads of a workgroup (one point
 struct Quot29Args {
     const Fr* cos;                 // [columns][ne]: coset values of the proof's columns (advice first), radix 2^261
     size_t ne;
-    const Fr *fixed_cos, *sigma_cos, *l0, *l_last, *l_active, *x_ext;      // the key's tables, radix 2^261
+    const Fr *fixed_cos, *sigma_cos, *l0, *l_last, *l_active;      // the key's tables, radix 2^261
+    const Fr* dx_ext;              // [permutation column c][ne]: delta^c x at the points x of the quotient domain, radix 2^261
     const Fr* consts;              // the plan's constants, radix 2^261
     uint32_t i_pin, i_pz, i_lz, i_inst;      // first permuted-input, permutation-product, lookup-product, instance column of `cos`
     uint32_t mask;                 // n - 1: index = coset * n + row, rotations move the row
     int32_t rot_last;
-    Fr y, theta, beta, gamma, delta;         // radix 2^261
+    // challenges, radix 2^261; 1 / beta and beta^(columns of a full / of the last permutation set) come with them
+    Fr y, theta, beta, gamma, beta_inv, beta_pow_full, beta_pow_last;
     Fr* h;                         // [ne] result, canonical, radix 2^256
 };
 
