@@ -1241,53 +1241,53 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         hipLaunchKernelGGL(pk->quot_fn, dim3(ne / qbs), dim3(qbs), 0, st, qa);
         pr->timers.end(st);
     } else {
-    extended_domain(pa);
-    pa.mult = y; pa.acc_in = nullptr;
-    pa.prog = pk->gate_prog; pa.n_instr = (uint32_t)P.gate_prog.size(); pa.nslots = P.gate_slots;
-    pa.out = pr->h;
-    pr->timers.begin(KID_PROG, st);
-    if (pk->gate_fn) hipLaunchKernelGGL(pk->gate_fn, dim3(ne / PROG_THREADS), dim3(PROG_THREADS), 0, st, pa);
-    else launch_prog(st, pa, ne, pr->throughput);
-    pr->timers.end(st);
-    // the theta-compressed input and table of lookup l on the quotient domain, then its terms -- for the first lookup in
-    // the same pass as the permutation terms
-    auto lookup_args = [&](uint32_t l) {
-        const LookupPlan& lk = P.lookups[l];
         extended_domain(pa);
-        pa.mult = theta; pa.acc_in = nullptr;
-        pa.prog = pk->lk_in_prog[l]; pa.n_instr = (uint32_t)lk.in_prog.size(); pa.nslots = lk.in_slots;
-        pa.out = pr->aux_ext;
-        ProgArgs pt = pa;
-        pt.prog = pk->lk_tab_prog[l]; pt.n_instr = (uint32_t)lk.tab_prog.size(); pt.nslots = lk.tab_slots;
-        pt.out = pr->aux_ext + ne;
-        launch_prog(st, pa, ne, pr->throughput, &pt);
-        LookupQArgs q;
-        q.z = CS(I_LZ + l); q.pin = CS(I_PIN + 2 * l); q.ptab = CS(I_PIN + 2 * l + 1);
-        q.ain = pr->aux_ext; q.stab = pr->aux_ext + ne;
-        q.l0 = pk->l0; q.l_last = pk->l_last; q.l_active = pk->l_active;
-        q.mask = n - 1; q.y = y; q.beta = beta; q.gamma = gamma; q.h = pr->h;
-        return q;
-    };
-    uint32_t l_first = 0;
-    if (S) {
-        PermQArgs q;
-        q.p = pg;
-        q.p.sigma = pk->sigma_cos; q.p.sigma_stride = ne; q.p.xs = pk->x_ext;
-        for (uint32_t c = 0; c < PC; c++) {
-            uint32_t t = P.perm_cols[c].first, ix = P.perm_cols[c].second;
-            q.p.col[c] = t == COL_ADVICE ? CS(ix) : t == COL_FIXED ? pk->fixed_cos + (size_t)ix * ne : CS(I_INST);
+        pa.mult = y; pa.acc_in = nullptr;
+        pa.prog = pk->gate_prog; pa.n_instr = (uint32_t)P.gate_prog.size(); pa.nslots = P.gate_slots;
+        pa.out = pr->h;
+        pr->timers.begin(KID_PROG, st);
+        if (pk->gate_fn) hipLaunchKernelGGL(pk->gate_fn, dim3(ne / PROG_THREADS), dim3(PROG_THREADS), 0, st, pa);
+        else launch_prog(st, pa, ne, pr->throughput);
+        pr->timers.end(st);
+        // the theta-compressed input and table of lookup l on the quotient domain, then its terms -- for the first lookup in
+        // the same pass as the permutation terms
+        auto lookup_args = [&](uint32_t l) {
+            const LookupPlan& lk = P.lookups[l];
+            extended_domain(pa);
+            pa.mult = theta; pa.acc_in = nullptr;
+            pa.prog = pk->lk_in_prog[l]; pa.n_instr = (uint32_t)lk.in_prog.size(); pa.nslots = lk.in_slots;
+            pa.out = pr->aux_ext;
+            ProgArgs pt = pa;
+            pt.prog = pk->lk_tab_prog[l]; pt.n_instr = (uint32_t)lk.tab_prog.size(); pt.nslots = lk.tab_slots;
+            pt.out = pr->aux_ext + ne;
+            launch_prog(st, pa, ne, pr->throughput, &pt);
+            LookupQArgs q;
+            q.z = CS(I_LZ + l); q.pin = CS(I_PIN + 2 * l); q.ptab = CS(I_PIN + 2 * l + 1);
+            q.ain = pr->aux_ext; q.stab = pr->aux_ext + ne;
+            q.l0 = pk->l0; q.l_last = pk->l_last; q.l_active = pk->l_active;
+            q.mask = n - 1; q.y = y; q.beta = beta; q.gamma = gamma; q.h = pr->h;
+            return q;
+        };
+        uint32_t l_first = 0;
+        if (S) {
+            PermQArgs q;
+            q.p = pg;
+            q.p.sigma = pk->sigma_cos; q.p.sigma_stride = ne; q.p.xs = pk->x_ext;
+            for (uint32_t c = 0; c < PC; c++) {
+                uint32_t t = P.perm_cols[c].first, ix = P.perm_cols[c].second;
+                q.p.col[c] = t == COL_ADVICE ? CS(ix) : t == COL_FIXED ? pk->fixed_cos + (size_t)ix * ne : CS(I_INST);
+            }
+            q.pz = CS(I_PZ);
+            q.l0 = pk->l0; q.l_last = pk->l_last; q.l_active = pk->l_active;
+            q.n_sets = S; q.mask = n - 1; q.stride = ne; q.rot_last = P.rot_last; q.y = y; q.h = pr->h;
+            LookupQArgs lq = {};
+            if (L) { lq = lookup_args(0); l_first = 1; }
+            hipLaunchKernelGGL(perm_quotient_kernel, dim3(ne / ebs), dim3(ebs), 0, st, q, lq, L ? 1u : 0u);
         }
-        q.pz = CS(I_PZ);
-        q.l0 = pk->l0; q.l_last = pk->l_last; q.l_active = pk->l_active;
-        q.n_sets = S; q.mask = n - 1; q.stride = ne; q.rot_last = P.rot_last; q.y = y; q.h = pr->h;
-        LookupQArgs lq = {};
-        if (L) { lq = lookup_args(0); l_first = 1; }
-        hipLaunchKernelGGL(perm_quotient_kernel, dim3(ne / ebs), dim3(ebs), 0, st, q, lq, L ? 1u : 0u);
-    }
-    for (uint32_t l = l_first; l < L; l++) {
-        const LookupQArgs q = lookup_args(l);
-        hipLaunchKernelGGL(lookup_quotient_kernel, dim3(ne / ebs), dim3(ebs), 0, st, q);
-    }
+        for (uint32_t l = l_first; l < L; l++) {
+            const LookupQArgs q = lookup_args(l);
+            hipLaunchKernelGGL(lookup_quotient_kernel, dim3(ne / ebs), dim3(ebs), 0, st, q);
+        }
     }
     // per-coset interpolants, then the nc x nc solve per coefficient: the quotient pieces [nc][n] (in the buffer
     // the lookup compression no longer needs)
