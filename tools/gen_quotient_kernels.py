@@ -44,6 +44,7 @@ PINV29 = (-pow(P, -1, 1 << 29)) & M29
 MUL_SHRINK = 164                      # p / 2^261 < 1 / 164 (lazy29.hip.hpp)
 V_MUL_MAX = 160                       # operands of a product: value below 160 p keeps the top limb below 2^29
 V_ADD_MAX = 1000                      # the top limb is a 32-bit word: value < 2^264 ~ 1290 p
+SECTION_MIN_LOADS = int(os.environ.get("QUOT29_SECTION_MIN_LOADS", "12"))    # gates are grouped into sections of at least this many loads
 
 
 # ------------------------------------------------------------------------------------------------ plan parsing
@@ -217,6 +218,7 @@ class Emitter:
         self.loads = {}               # pointer expression -> Val
         self.source = source          # self-check: pointer expression -> stored 256-bit value (canonical, radix 2^261)
         self.n_mul = self.n_add = self.n_norm = self.n_red = 0
+        self.n_loads_since_barrier = 0
 
     # -- bookkeeping
     def fresh(self):
@@ -238,9 +240,14 @@ class Emitter:
             self.kps[(K, S)] = "KP_%d_%d" % (K, S)
         return self.kps[(K, S)]
 
-    def barrier(self):
+    def barrier(self, min_loads=0):
         """Forget the loaded values: a later use loads again instead of holding nine registers across hundreds of
-        operations (the compiler barrier keeps the compiler from merging the two loads back into one)."""
+        operations (the compiler barrier keeps the compiler from merging the two loads back into one).  Every barrier
+        is also a stall -- the loads after it cannot start before it -- so short sections (fewer than `min_loads`
+        loads since the last barrier) are merged with what follows."""
+        if self.n_loads_since_barrier < min_loads:
+            return
+        self.n_loads_since_barrier = 0
         self.lines.append('    asm volatile("" ::: "memory");')
         self.loads = {k: v for k, v in self.loads.items() if k == "ONE" or k.startswith("a.") and " " not in k}
 
@@ -249,6 +256,7 @@ class Emitter:
         if ptr in self.loads:
             return self.loads[ptr]
         name = self.fresh()
+        self.n_loads_since_barrier += 1
         self.lines.append("    const E29 %s = ld29(%s);" % (name, ptr))
         c = m = None
         if self.source is not None:
@@ -432,7 +440,7 @@ def emit_program(em, pl, slots, prog, mult, what):
         elif op == OP_NEG:
             s[dst] = em.neg(s[x])
         elif op == OP_OUT:
-            em.barrier()
+            em.barrier(SECTION_MIN_LOADS)
             if i in runs:
                 rid, pos, length, w, expr_slot, (col, rot) = runs[i]
                 inner = gate_val[i] if pos == 0 else fold(inner, gate_val[i])
