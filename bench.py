@@ -198,6 +198,11 @@ def main():
     ctx = shp.Context(local_rank)
     plan, lay = circuits.build_withdraw_plan()                 # k = 13, height 13, 12-bit range table
     params = shp.Params.synthetic(ctx, 13, TAU)
+    # window width and HBM bytes of the two multiples tables the commitments gather from
+    msm_tables = {}
+    for label, basis in (("lagrange", shp.BASIS_LAGRANGE), ("monomial", shp.BASIS_MONOMIAL)):
+        direct, c, nbytes = params.msm_info(basis)
+        msm_tables[label] = {"direct": bool(direct), "window_bits": int(c), "GB": round(nbytes / 1e9, 1)}
     pk = shp.ProvingKey(ctx, params, plan)
     make_wit = lambda rnd_: b"".join(int(x).to_bytes(32, "little")
                                      for x in circuits.withdraw_witness_inputs(lay, shp.poseidon2_hash_host, rnd_))
@@ -364,6 +369,7 @@ def main():
                    "proofs_per_step": proofs_per_step_all, "proofs_per_step_rank0": per_step, "lanes": a.lanes, "k": 13,
                    "host_cores_per_rank": share, "host_cores_visible": cores,
                    "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "event_lanes": a.event_lanes,
+                   "msm_tables": msm_tables,
                    "blocking_sync": os.environ.get("SHP_BLOCKING_SYNC") == "1",
                    "parallelism": f"proofs sharded over {n_gpus} GPU(s), no data-path collective, gloo barrier"},
         "verified": verified,
