@@ -132,8 +132,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--lanes", type=int, default=48, help="concurrent proving lanes (streams) per GPU "
                     "(measured on one MI355X: 1694 / 1721 / 1764 / 1768 proofs/s at 24 / 32 / 48 / 64)")
-    ap.add_argument("--proofs-per-lane", type=int, default=8, help="proofs each lane produces back to back in one step (a step "
-                    "ends when its last proof does: lanes idle at the tail -- 1945 / 1984 / 2025 proofs/s at 4 / 8 / 16)")
+    ap.add_argument("--proofs-per-lane", type=int, default=16, help="proofs each lane produces back to back in one step (a step "
+                    "ends when its last proof does: lanes idle at the tail -- 2220 / 2300 / 2310 proofs/s at 8 / 16 / 32)")
     ap.add_argument("--latency-proofs", type=int, default=100, help="single-lane proofs timed for p50 (the metric's latency half: 100 runs)")
     ap.add_argument("--cpu-proofs", type=int, default=3, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--batch", type=int, default=0, help="strong-scaling mode: one step = this many distinct proofs sharded "
