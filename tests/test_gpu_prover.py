@@ -296,6 +296,7 @@ def test_new_account_shaped_plan_proof_and_serve(shp, oracle, gpu_ctx):
     params = shp.Params.synthetic(gpu_ctx, 9, TAU)
     pk = shp.ProvingKey(gpu_ctx, params, plan_bytes)
     assert (pk.n_inputs, pk.n_instances) == (9, 13)
+    assert pk.compiled_level() == 2, "the NewAccount-shaped plan is shipped with its generated quotient kernel"
     wit = C.new_account_witness_inputs(lay, random.Random(6), 2**31 + 9)
     pr = shp.Prover(pk)
     proof, inst = pr.prove(wit, bytes([8]) * 32)
