@@ -168,20 +168,29 @@ class Server:
         heights = {b.n_height for b in self.backends.values() if b.n_height}      # NewAccount has no Merkle path
         if self.native is None or len(heights) > 1:
             return encode_frame(await self.handle_request(loads_strict(body), loop))
+        # decode, prove and encode in ONE executor job: the event-loop thread only moves frames (two hops per request
+        # through the loop cost it a tenth of a millisecond each, and it is the thread every connection shares)
+        kind, out = await loop.run_in_executor(None, self._serve_native, body, heights.pop() if heights else 0)
+        if kind != self.native.TEE_GENERATE_PROOF:
+            return encode_frame(await self.handle_request("Ping" if kind == self.native.TEE_PING else "TeePublicKey", loop))
+        self.served += 1
+        return out
+
+    def _serve_native(self, body: bytes, height: int):
+        """(request kind, response frame of a GenerateProof request) -- runs on an executor thread; the library calls
+        release the GIL"""
         try:
-            kind, ctype, wit = await loop.run_in_executor(None, self.native.tee_decode_request, body,
-                                                          heights.pop() if heights else 0)
+            kind, ctype, wit = self.native.tee_decode_request(body, height)
         except self.native.ShpError as e:
             raise ProtocolError(str(e))
         if kind != self.native.TEE_GENERATE_PROOF:
-            return encode_frame(await self.handle_request("Ping" if kind == self.native.TEE_PING else "TeePublicKey", loop))
+            return kind, None
         backend = self.backends.get(ctype)
         if backend is None:
             raise ProtocolError(f"circuit {ctype}: no proving key loaded")
-        proof, instances = await loop.run_in_executor(None, backend.prove, wit, self.seed_source(32))
-        self.served += 1
+        proof, instances = backend.prove(wit, self.seed_source(32))
         body_out = self.native.tee_encode_proof_response(ctype, proof, instances)
-        return struct.pack(">I", len(body_out)) + body_out
+        return kind, struct.pack(">I", len(body_out)) + body_out
 
     async def handle_client(self, reader, writer):
         loop = asyncio.get_running_loop()
