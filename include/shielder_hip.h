@@ -375,6 +375,29 @@ int32_t shp_prove_batch(shp_pool* p, const uint8_t* witnesses_le32, size_t n_inp
                         uint8_t* proofs_out, size_t proof_stride, size_t* proof_lens, uint8_t* instances_le32,
                         size_t instances_stride);
 int32_t shp_pool_stats(const shp_pool* p, uint64_t* proofs_done, uint64_t* queued);
+/* the shape of the pool's key: witness inputs per proof, public inputs, proof length in bytes */
+int32_t shp_pool_info(const shp_pool* p, uint32_t* n_witness_inputs, uint32_t* n_instances, uint32_t* proof_len);
+
+/* ---- native serve loop: TCP front of the proving pools ---------------------------------
+ * Server::handle_client of the reference's enclave server (/root/reference/tee/crates/shielder-prover-tee/src/
+ * server.rs:69-90) over TCP: per connection a sequence of length-delimited requests (4-byte big-endian length,
+ * tokio_util LengthDelimitedCodec as in tee/crates/shielder-prover-common/src/vsock.rs:69-102, at most 8 MiB),
+ * Ping -> Pong, TeePublicKey -> empty key and attestation (ECIES / attestation are out of scope), GenerateProof ->
+ * EncryptedProof from the pool registered for the payload's CircuitType; a malformed frame, an unknown circuit type
+ * or a failed proof ends the connection, as any error does in the reference (server.rs:70-73).  Frames are decoded
+ * and answered by shp_tee_decode_request / shp_tee_encode_proof_response, one thread per connection; blinding
+ * seeds come from getrandom(2) (the reference: rand::thread_rng(), circuits/withdraw.rs:112).
+ * pools[i] serves circuits[i] (SHP_TEE_NEW_ACCOUNT / _DEPOSIT / _WITHDRAW, each at most once; n_pools may be 0: the
+ * server then answers Ping and TeePublicKey only); merkle_height as for shp_tee_decode_request; bind_addr a dotted
+ * IPv4 address (NULL = 127.0.0.1); port 0 = any free port (shp_server_port reports it).  The pools must outlive
+ * the server.  shp_server_stop closes the listener and every connection, joins the threads and frees the server. */
+typedef struct shp_server shp_server;
+int32_t shp_server_start(shp_pool* const* pools, const int32_t* circuits, uint32_t n_pools, uint32_t merkle_height,
+                         const char* bind_addr, uint16_t port, shp_server** out);
+int32_t shp_server_port(const shp_server* s, uint16_t* port);
+/* proofs answered, connections ended by an error, connections accepted */
+int32_t shp_server_stats(const shp_server* s, uint64_t* served, uint64_t* failed, uint64_t* connections);
+int32_t shp_server_stop(shp_server* s);
 
 /* ---- diagnostics ------------------------------------------------------------------- */
 /* sustained Fr Montgomery products per second with every CU busy: the integer-ALU ceiling that

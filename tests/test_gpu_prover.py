@@ -253,13 +253,52 @@ def test_serve_end_to_end(shp, oracle, gpu_ctx):
 
     resps = asyncio.run(run())
     _, oinst = PL.synthesize(plan, wit)
-    for r in resps:
-        proof = base64.b64decode(r["EncryptedProof"]["proof"])
-        pub = json.loads(base64.b64decode(r["EncryptedProof"]["pub_inputs"]))
-        inst = [int.from_bytes(bytes(pub[f]), "little") for f in S.WITHDRAW_PUB_FIELDS]
-        assert inst == list(oinst)
-        assert PL.verify(opk, proof, inst, tau=TAU)
-    assert len({r["EncryptedProof"]["proof"] for r in resps}) == 3       # fresh randomness per request
+
+    def check(resps):
+        for r in resps:
+            proof = base64.b64decode(r["EncryptedProof"]["proof"])
+            pub = json.loads(base64.b64decode(r["EncryptedProof"]["pub_inputs"]))
+            inst = [int.from_bytes(bytes(pub[f]), "little") for f in S.WITHDRAW_PUB_FIELDS]
+            assert inst == list(oinst)
+            assert PL.verify(opk, proof, inst, tau=TAU)
+        assert len({r["EncryptedProof"]["proof"] for r in resps}) == len(resps)       # fresh randomness per request
+
+    check(resps)
+    # the same requests against the library's own TCP front (shp_server): no interpreter in the request path
+    native = shp.NativeServer({"Withdraw": pool}, h)
+
+    async def run_native():
+        async def session():                                 # one connection, several requests in sequence
+            reader, writer = await asyncio.open_connection("127.0.0.1", native.port)
+            out = []
+            for r in ("Ping", req, req):
+                writer.write(S.encode_frame(r))
+                await writer.drain()
+                out.append(await S.read_frame(reader))
+            writer.close()
+            return out
+        return await asyncio.gather(session(), session())
+
+    sessions = asyncio.run(run_native())
+    assert all(s[0] == "Pong" for s in sessions)
+    check([r for s in sessions for r in s[1:]])
+    assert native.stats() == (4, 0, 2)
+    # a field element that is not canonical (vec_to_f panics on it in the reference): the connection ends, the server
+    # keeps serving
+    bad_inputs = dict(inputs, value=[255] * 32)
+    bad_payload = {"circuit_type": "Withdraw", "user_public_key": [], "circuit_inputs": list(json.dumps(bad_inputs).encode())}
+
+    async def run_bad():
+        reader, writer = await asyncio.open_connection("127.0.0.1", native.port)
+        writer.write(S.encode_frame({"GenerateProof": {"payload": list(json.dumps(bad_payload).encode())}}))
+        await writer.drain()
+        gone = await reader.read(4)
+        writer.close()
+        return gone, await S.request("127.0.0.1", native.port, "Ping")
+
+    gone, pong = asyncio.run(run_bad())
+    assert gone == b"" and pong == "Pong"
+    native.close()
     pool.close(); pk.close(); params.close()
 
 

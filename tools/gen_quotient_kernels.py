@@ -219,11 +219,17 @@ class Emitter:
         self.source = source          # self-check: pointer expression -> stored 256-bit value (canonical, radix 2^261)
         self.n_mul = self.n_add = self.n_norm = self.n_red = 0
         self.n_loads_since_barrier = 0
+        self.used = set()             # names that appear as an operand (a leaf whose only consumer was folded away is dead)
+        self.leaves = []
 
     # -- bookkeeping
     def fresh(self):
         self.n += 1
         return "t%d" % self.n
+
+    def use(self, *vals):
+        for v in vals:
+            self.used.add(v.name)
 
     def check(self, v):
         if v.c is None:
@@ -257,6 +263,7 @@ class Emitter:
             return self.loads[ptr]
         name = self.fresh()
         self.n_loads_since_barrier += 1
+        self.leaves.append(name)
         self.lines.append("    const E29 %s = ld29(%s);" % (name, ptr))
         c = m = None
         if self.source is not None:
@@ -300,6 +307,7 @@ class Emitter:
         if a.L == 1:
             return a
         self.n_norm += 1
+        self.use(a)
         name = self.fresh()
         self.lines.append("    E29 %s = %s; R29::normalise(%s);" % (name, a.name, name))
         return self.check(Val(name, a.V, 1, c_normalise(a.c) if a.c is not None else None, a.m))
@@ -320,6 +328,7 @@ class Emitter:
         if a.L + b.L > 4:
             a, b = (self.normalised(a), b) if a.L >= b.L else (a, self.normalised(b))
         self.n_add += 1
+        self.use(a, b)
         name = self.fresh()
         self.lines.append("    const E29 %s = add29(%s, %s);" % (name, a.name, b.name))
         c = [x + y for x, y in zip(a.c, b.c)] if a.c is not None else None
@@ -338,6 +347,7 @@ class Emitter:
         if a.V + K > V_ADD_MAX:
             a = self.reduced(a)
         self.n_add += 1
+        self.use(a, b)
         name = self.fresh()
         if a.zero:
             self.lines.append("    const E29 %s = neg29(%s, %s);" % (name, b.name, self.kp(K, S)))
@@ -366,6 +376,7 @@ class Emitter:
         if a is b or a.name == b.name:
             a = self.normalised(a)
             self.n_mul += 1
+            self.use(a)
             name = self.fresh()
             self.lines.append("    const E29 %s = R29::sqr(%s);" % (name, a.name))
             c = c_sqr(a.c) if a.c is not None else None
@@ -376,6 +387,7 @@ class Emitter:
             else:
                 b = self.normalised(b)
         self.n_mul += 1
+        self.use(a, b)
         name = self.fresh()
         self.lines.append("    const E29 %s = R29::mul(%s, %s);" % (name, a.name, b.name))
         c = c_mul(a.c, b.c) if a.c is not None else None
@@ -523,6 +535,9 @@ def emit_quotient(em, pl):
         h = em.reduced(h)
     if h.L > 4:
         h = em.normalised(h)
+    em.use(h)
+    dead = {n for n in em.leaves if n not in em.used}       # e.g. a selector loaded by the program and applied once per run instead
+    em.lines = [l for l in em.lines if not any(l.startswith("    const E29 %s = ld29(" % n) for n in dead)]
     em.lines.append("    st(a.h + i, R29::to_fp(%s));" % h.name)
     return h
 

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--clients", type=int, default=48)
     ap.add_argument("--requests", type=int, default=20)
     ap.add_argument("--lanes", type=int, default=16)
+    ap.add_argument("--native", action="store_true", help="the library's own TCP front (shp_server) instead of serve.py's asyncio loop")
     ap.add_argument("--client-procs", type=int, default=0, help="run the clients in this many processes of their own instead of "
                                                                 "inside the server's interpreter (0 = in-process)")
     a = ap.parse_args()
@@ -62,6 +63,7 @@ def main():
     shp = importlib.import_module("zkos-monorepo_amd")
     circuits = importlib.import_module("zkos-monorepo_amd.circuits")
     S = importlib.import_module("zkos-monorepo_amd.serve")
+    shp.prefer_sleeping_waits(a.lanes)
     ctx = shp.Context(0)
     plan, lay = circuits.build_withdraw_plan()
     params = shp.Params.synthetic(ctx, 13, 0xDEADBEEF12345678)
@@ -95,8 +97,20 @@ def main():
         loop = asyncio.get_running_loop()
         from concurrent.futures import ThreadPoolExecutor
         loop.set_default_executor(ThreadPoolExecutor(max_workers=max(32, 2 * a.lanes)))
-        srv = await S.Server(S.PoolBackend(pool, h)).serve(port=0)
-        port = srv.sockets[0].getsockname()[1]
+        if a.native:
+            native = shp.NativeServer({"Withdraw": pool}, h)
+            port = native.port
+
+            class _Ctx:                                   # same shape as the asyncio server below
+                async def __aenter__(self):
+                    return self
+
+                async def __aexit__(self, *exc):
+                    native.close()
+            srv = _Ctx()
+        else:
+            srv = await S.Server(S.PoolBackend(pool, h)).serve(port=0)
+            port = srv.sockets[0].getsockname()[1]
         async with srv:
             if procs:
                 for _, conn in procs:
@@ -118,7 +132,7 @@ def main():
     el = asyncio.run(run())
     lat.sort()
     n = len(lat)
-    print(json.dumps({"serve_path": "TCP + TEE JSON framing + shp_pool", "clients": a.clients, "client_processes": a.client_procs,
+    print(json.dumps({"serve_path": "TCP + TEE JSON framing + shp_pool", "front": "native (shp_server)" if a.native else "serve.py (asyncio)", "clients": a.clients, "client_processes": a.client_procs,
                       "lanes": a.lanes, "requests": n,
                       "request_bytes": len(reqs[0]), "proofs_per_s": n / el, "latency_ms_p50": 1e3 * lat[n // 2],
                       "latency_ms_p99": 1e3 * lat[min(n - 1, int(n * 0.99))], "latency_ms_mean": 1e3 * statistics.mean(lat)}))

@@ -692,3 +692,52 @@ def tee_encode_proof_response(circuit: str, proof: bytes, instances) -> bytes:
     _check(lib().shp_tee_encode_proof_response(C.c_int32(TEE_CIRCUITS.index(circuit)), C.c_char_p(proof), C.c_size_t(len(proof)),
                                                C.c_char_p(ins), C.c_size_t(len(ins) // 32), out, C.c_size_t(cap), C.byref(n)))
     return out.raw[:n.value]
+
+
+def host_cores() -> int:
+    """host cores this process can count on: the affinity mask, capped by the cgroup CPU quota"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 16)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def prefer_sleeping_waits(lanes: int) -> None:
+    """Call before the first Context: with more proving lanes than host cores, stream waits that spin starve the launch
+    threads (24 spinning lanes on 16 cores: 870 proofs/s, 1090 sleeping), so ask the library for sleeping waits
+    (SHP_BLOCKING_SYNC=1, read by shp_ctx_create) unless the environment already decides"""
+    if lanes > host_cores():
+        os.environ.setdefault("SHP_BLOCKING_SYNC", "1")
+
+
+class NativeServer:
+    """The library's own TCP front of the proving pools (shp_server, csrc/server.hip): the request loop of the reference's
+    enclave server (/root/reference/tee/crates/shielder-prover-tee/src/server.rs:69-90) without an interpreter in the
+    request path.  pools: {circuit type name: Pool}; may be empty (Ping / TeePublicKey only)."""
+
+    def __init__(self, pools: dict, height: int, host: str = "127.0.0.1", port: int = 0):
+        names = list(pools)
+        arr = (C.c_void_p * max(1, len(names)))(*[pools[n].h for n in names])
+        kinds = (C.c_int32 * max(1, len(names)))(*[TEE_CIRCUITS.index(n) for n in names])
+        self.pools = pools                               # the pools must outlive the server
+        self.h = C.c_void_p()
+        _check(lib().shp_server_start(arr, kinds, C.c_uint32(len(names)), C.c_uint32(height), C.c_char_p(host.encode()),
+                                      C.c_uint16(port), C.byref(self.h)))
+        p = C.c_uint16()
+        _check(lib().shp_server_port(self.h, C.byref(p)))
+        self.port = p.value
+
+    def stats(self):
+        """(proofs answered, connections ended by an error, connections accepted)"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().shp_server_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def close(self):
+        if self.h:
+            lib().shp_server_stop(self.h)
+            self.h = C.c_void_p()

@@ -245,6 +245,15 @@ int32_t shp_prove_batch(shp_pool* p, const uint8_t* witnesses_le32, size_t n_inp
     });
 }
 
+int32_t shp_pool_info(const shp_pool* p, uint32_t* n_witness_inputs, uint32_t* n_instances, uint32_t* proof_len) {
+    return shp::guarded([&] {
+        SHP_REQUIRE(p, SHP_ERR_INVALID_ARG, "pool_info: null pool");
+        if (n_witness_inputs) *n_witness_inputs = p->n_inputs;
+        if (n_instances) *n_instances = p->n_instances;
+        if (proof_len) *proof_len = p->proof_len;
+    });
+}
+
 int32_t shp_pool_stats(const shp_pool* p, uint64_t* proofs_done, uint64_t* queued) {
     return shp::guarded([&] {
         SHP_REQUIRE(p, SHP_ERR_INVALID_ARG, "pool_stats: null pool");
