@@ -48,3 +48,70 @@ def test_cpp_host_over_the_c_abi_matches_oracle(oracle, tmp_path):
         want, inst = PL.prove(opk, srs, w, bytes([i + 1]) * 32)        # the CLI seeds proof i with byte i + 1
         assert got[i * plen:(i + 1) * plen] == want, f"proof {i} from the C++ host differs from the oracle"
         assert PL.verify(opk, want, inst, tau=TAU)
+
+
+def test_cpp_prover_server_answers_a_withdraw_request(oracle, tmp_path):
+    """examples/shp_serve.cpp -- SRS, key, pool and the library's request loop (shp_server_start) in a C++ process with no
+    Python in it -- started as a child: a Withdraw request in the TEE wire format over TCP comes back as an EncryptedProof
+    whose proof the restated verifier accepts for the circuit's public inputs; the server reports what it served"""
+    import base64
+    import socket
+    import struct
+    b = sys.modules.get("zkos-monorepo_amd.binding")
+    if b is not None and b.Context.created:
+        pytest.skip("this process has already initialised the GPU: it must not start another program")
+    exe = os.path.join(ROOT, "zkos-monorepo_amd", "shp_serve")
+    assert os.path.exists(exe), "zkos-monorepo_amd/shp_serve is not built (make -C zkos-monorepo_amd/csrc)"
+    PL = importlib.import_module("oracle.plonk")
+    C = importlib.import_module("zkos-monorepo_amd.circuits")
+    S = importlib.import_module("zkos-monorepo_amd.serve")
+    plan_bytes, lay = C.build_withdraw_plan(k=9, height=1, range_bits=4, range_chunks=8)
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    wit = C.withdraw_witness_inputs(lay, H, random.Random(31), 2**31 + 7, 2**20 + 9)
+    (tmp_path / "plan.bin").write_bytes(plan_bytes)
+    le = lambda x: list(int(x).to_bytes(32, "little"))
+    h = lay.height
+    inputs = {"id": le(wit[lay.ID]), "nullifier_old": le(wit[lay.NULLIFIER_OLD]), "account_balance_old": le(wit[lay.BALANCE_OLD]),
+              "token_address": le(wit[lay.TOKEN]), "path": [b for x in wit[4:4 + 7 * h] for b in le(x)], "value": le(wit[lay.VALUE]),
+              "nullifier_new": le(wit[lay.NULLIFIER_NEW]), "commitment": le(wit[lay.COMMITMENT]), "mac_salt": le(wit[lay.MAC_SALT])}
+    payload = {"circuit_type": "Withdraw", "user_public_key": [], "circuit_inputs": list(json.dumps(inputs).encode())}
+    frame = S.encode_frame({"GenerateProof": {"payload": list(json.dumps(payload).encode())}})
+    proc = subprocess.Popen([exe, "9", "%x" % TAU, "2", "0", str(h), "Withdraw=" + str(tmp_path / "plan.bin")],
+                            stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        hello = json.loads(proc.stdout.readline())
+        port = hello["listening"]
+        assert port > 0 and hello["circuits"] == 1
+
+        def exchange(sock, body_frame):
+            sock.sendall(body_frame)
+            hdr = b""
+            while len(hdr) < 4:
+                chunk = sock.recv(4 - len(hdr))
+                assert chunk, "the server closed the connection"
+                hdr += chunk
+            (n,) = struct.unpack(">I", hdr)
+            body = b""
+            while len(body) < n:
+                body += sock.recv(n - len(body))
+            return json.loads(body)
+
+        with socket.create_connection(("127.0.0.1", port), timeout=60) as s:
+            assert exchange(s, S.encode_frame("Ping")) == "Pong"
+            resps = [exchange(s, frame) for _ in range(2)]
+    finally:
+        proc.stdin.close()                                         # the server runs until its stdin closes
+        out, err = proc.stdout.read(), proc.stderr.read()
+        proc.wait(timeout=60)
+    assert proc.returncode == 0, err[-2000:]
+    assert json.loads(out.strip().splitlines()[-1]) == {"served": 2, "failed": 0, "connections": 1}
+    plan = PL.Plan(plan_bytes)
+    opk = PL.keygen(plan, oracle.srs_synthetic(9, TAU))
+    _, oinst = PL.synthesize(plan, wit)
+    for r in resps:
+        proof = base64.b64decode(r["EncryptedProof"]["proof"])
+        pub = json.loads(base64.b64decode(r["EncryptedProof"]["pub_inputs"]))
+        inst = [int.from_bytes(bytes(pub[f]), "little") for f in S.WITHDRAW_PUB_FIELDS]
+        assert inst == list(oinst)
+        assert PL.verify(opk, proof, inst, tau=TAU)
+    assert resps[0]["EncryptedProof"]["proof"] != resps[1]["EncryptedProof"]["proof"]      # fresh randomness per request
