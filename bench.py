@@ -67,6 +67,8 @@ def kernel_source_id():
     d = os.path.join(ROOT, "zkos-monorepo_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".hpp", ".inc")):
+            if f in ("wire.hip", "server.hip", "verify.hip", "plancompile.hip"):
+                continue                                     # host-only translation units: no kernel, no launch
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

@@ -385,7 +385,8 @@ int32_t shp_pool_info(const shp_pool* p, uint32_t* n_witness_inputs, uint32_t* n
  * Ping -> Pong, TeePublicKey -> empty key and attestation (ECIES / attestation are out of scope), GenerateProof ->
  * EncryptedProof from the pool registered for the payload's CircuitType; a malformed frame, an unknown circuit type
  * or a failed proof ends the connection, as any error does in the reference (server.rs:70-73).  Frames are decoded
- * and answered by shp_tee_decode_request / shp_tee_encode_proof_response, one thread per connection; blinding
+ * and answered by shp_tee_decode_request / shp_tee_encode_proof_response, one thread per connection (at most 1024
+ * connections at a time: further peers are closed at once and counted as failed); blinding
  * seeds come from getrandom(2) (the reference: rand::thread_rng(), circuits/withdraw.rs:112).
  * pools[i] serves circuits[i] (SHP_TEE_NEW_ACCOUNT / _DEPOSIT / _WITHDRAW, each at most once; n_pools may be 0: the
  * server then answers Ping and TeePublicKey only); merkle_height as for shp_tee_decode_request; bind_addr a dotted

@@ -34,6 +34,7 @@
 namespace {
 constexpr size_t MAX_FRAME = 8u * 1024 * 1024;          // LengthDelimitedCodec's default max_frame_length
 constexpr size_t MAX_WITNESS_INPUTS = 4096;
+constexpr size_t MAX_CONNECTIONS = 1024;                // a thread each: further peers are turned away until one leaves
 
 bool read_exact(int fd, uint8_t* p, size_t n) {
     while (n) {
@@ -171,6 +172,11 @@ struct shp_server {
                 } else {
                     i++;
                 }
+            }
+            if (conns.size() >= MAX_CONNECTIONS) {
+                ::close(fd);
+                errors++;
+                continue;
             }
             conns.emplace_back(new Conn);
             Conn* c = conns.back().get();
