@@ -249,7 +249,11 @@ def main():
     # carrying them the pool proves 8 % fewer proofs (measured: 1420 with 16, 1520 with 1, 1545 with none)
     for pr in provers[:a.event_lanes]:
         pr.profile(True)
+    cpu0 = os.times()
     elapsed = run_steps(step, a.steps, 0, sync, barrier)
+    cpu1 = os.times()
+    # share of this rank's host cores the timed region kept busy (lane threads, witness programs, transcript hashing)
+    host_cpu_util = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(1e-9, elapsed * max(1, share))
     prof = {}
     for pr in provers:
         for name, (cnt, ms) in pr.profile_read().items():
@@ -369,7 +373,7 @@ def main():
         "config": {"workload": ("batch of %d independent 2^13 withdraw-shaped proofs sharded over the ranks" % a.batch) if a.batch else
                                "2^13 withdraw-shaped circuit plan (stand-in), KZG/SHPLONK proof, synthetic k=13 SRS",
                    "proofs_per_step": proofs_per_step_all, "proofs_per_step_rank0": per_step, "lanes": a.lanes, "k": 13,
-                   "host_cores_per_rank": share, "host_cores_visible": cores,
+                   "host_cores_per_rank": share, "host_cores_visible": cores, "host_cpu_util_rank0": round(host_cpu_util, 3),
                    "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "event_lanes": a.event_lanes,
                    "msm_tables": msm_tables,
                    "blocking_sync": os.environ.get("SHP_BLOCKING_SYNC") == "1",
