@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Soak: N proofs through a 16-lane pool, EVERY proof checked by the native verifier (pairing included) and the public
-inputs against shp_public_inputs.   python tools/soak.py [--proofs 20000] [--lanes 16]"""
+inputs against shp_public_inputs.   python tools/soak.py [--proofs 20000] [--lanes 16] [--serve]
+--serve: the proofs are requested over TCP in the TEE wire format from the library's own request loop (shp_server), one
+connection per lane, and checked the same way."""
 import argparse, importlib, os, random, sys, time
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +15,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--proofs", type=int, default=20000)
     ap.add_argument("--lanes", type=int, default=16)
+    ap.add_argument("--serve", action="store_true")
     a = ap.parse_args()
+    shp.prefer_sleeping_waits(a.lanes)
     ctx = shp.Context(0)
     plan, lay = circuits.build_withdraw_plan()
     params = shp.Params.synthetic(ctx, 13, 0xDEADBEEF12345678)
@@ -38,6 +42,50 @@ def main():
         if inst != pubs[i % 16] or not pk.verify(proof, inst):
             bad[0] += 1
 
+    if a.serve:
+        import base64, json, socket, struct
+        S = importlib.import_module("zkos-monorepo_amd.serve")
+        le = lambda x: list(int(x).to_bytes(32, "little"))
+        h = lay.height
+        frames = []
+        for wit in wits:
+            inputs = {"id": le(wit[lay.ID]), "nullifier_old": le(wit[lay.NULLIFIER_OLD]), "account_balance_old": le(wit[lay.BALANCE_OLD]),
+                      "token_address": le(wit[lay.TOKEN]), "path": [b for x in wit[4:4 + 7 * h] for b in le(x)], "value": le(wit[lay.VALUE]),
+                      "nullifier_new": le(wit[lay.NULLIFIER_NEW]), "commitment": le(wit[lay.COMMITMENT]), "mac_salt": le(wit[lay.MAC_SALT])}
+            payload = {"circuit_type": "Withdraw", "user_public_key": [], "circuit_inputs": list(json.dumps(inputs).encode())}
+            frames.append(S.encode_frame({"GenerateProof": {"payload": list(json.dumps(payload).encode())}}))
+        server = shp.NativeServer({"Withdraw": pool}, h)
+
+        def connection(c):                                   # requests c, c + lanes, c + 2 lanes, ... on one connection
+            sock = socket.create_connection(("127.0.0.1", server.port), timeout=120)
+            for i in range(c, a.proofs, a.lanes):
+                sock.sendall(frames[i % 16])
+                hdr = b""
+                while len(hdr) < 4:
+                    hdr += sock.recv(4 - len(hdr))
+                (n,) = struct.unpack(">I", hdr)
+                body = bytearray()
+                while len(body) < n:
+                    body += sock.recv(n - len(body))
+                r = json.loads(bytes(body))["EncryptedProof"]
+                pub = json.loads(base64.b64decode(r["pub_inputs"]))
+                inst = [int.from_bytes(bytes(pub[f]), "little") for f in S.WITHDRAW_PUB_FIELDS]
+                if inst != pubs[i % 16] or not pk.verify(base64.b64decode(r["proof"]), inst):
+                    bad[0] += 1
+            sock.close()
+
+        t0 = time.time()
+        with ThreadPoolExecutor(max_workers=a.lanes) as ex:
+            list(ex.map(connection, range(a.lanes)))
+        el = time.time() - t0
+        served, failed, conns = server.stats()
+        server.close()
+        if (served, failed, conns) != (a.proofs, 0, a.lanes):
+            bad[0] += 1
+        print(f"soak over TCP (shp_server): {a.proofs} requests on {a.lanes} connections in {el:.1f} s "
+              f"({a.proofs / el:.0f}/s incl. verification), server counted {served} served / {failed} failed, {bad[0]} bad")
+        pool.close(); pk.close(); params.close()
+        sys.exit(1 if bad[0] else 0)
     t0 = time.time()
     with ThreadPoolExecutor(max_workers=3 * a.lanes) as ex:
         list(ex.map(one, range(a.proofs)))
