@@ -44,6 +44,11 @@ PINV29 = (-pow(P, -1, 1 << 29)) & M29
 MUL_SHRINK = 164                      # p / 2^261 < 1 / 164 (lazy29.hip.hpp)
 V_MUL_MAX = 160                       # operands of a product: value below 160 p keeps the top limb below 2^29
 V_ADD_MAX = 1000                      # the top limb is a 32-bit word: value < 2^264 ~ 1290 p
+# Leaves whose loads are in flight ahead of the one in use.  Left to itself the compiler puts every load next to its use (it
+# is short of registers) and the wave then waits out the memory latency 144 times: half of a lone wave's time.  Measured in the
+# pool: 2295 / 2337 / 2351 / 2345 proofs/s at 0 / 3 / 4 / 6 (each leaf in flight holds eight registers; the kernels are capped
+# at 256 VGPRs -- two waves per SIMD -- and spill 28 bytes at 4, 100 at 6)
+PREFETCH_AHEAD = int(os.environ.get("QUOT29_PREFETCH_AHEAD", "4"))
 SECTION_MIN_LOADS = int(os.environ.get("QUOT29_SECTION_MIN_LOADS", "12"))    # gates are grouped into sections of at least this many loads
 
 
@@ -221,6 +226,9 @@ class Emitter:
         self.n_loads_since_barrier = 0
         self.used = set()             # names that appear as an operand (a leaf whose only consumer was folded away is dead)
         self.leaves = []
+        self.leaf_ptrs = []           # pointer expression of every leaf load, in program order
+        self.ahead = None             # second pass: the first pass's leaf_ptrs -- leaves are loaded PREFETCH_AHEAD loads early
+        self.raw_emitted = 0
 
     # -- bookkeeping
     def fresh(self):
@@ -264,7 +272,18 @@ class Emitter:
         name = self.fresh()
         self.n_loads_since_barrier += 1
         self.leaves.append(name)
-        self.lines.append("    const E29 %s = ld29(%s);" % (name, ptr))
+        k = len(self.leaf_ptrs)
+        self.leaf_ptrs.append(ptr)
+        if self.ahead is None:
+            self.lines.append("    const E29 %s = ld29(%s);" % (name, ptr))
+        else:
+            # the raw words of this leaf were requested PREFETCH_AHEAD leaves ago; request those of the leaves ahead now (the
+            # compiler barrier keeps each request where it is written instead of next to its use)
+            assert self.ahead[k] == ptr
+            for j in range(self.raw_emitted, min(k + PREFETCH_AHEAD + 1, len(self.ahead))):
+                self.lines.append('    const Fr raw%d = ld(%s); asm volatile("" ::: "memory");' % (j, self.ahead[j]))
+            self.raw_emitted = max(self.raw_emitted, min(k + PREFETCH_AHEAD + 1, len(self.ahead)))
+            self.lines.append("    const E29 %s = R29::split<0>(raw%d);" % (name, k))
         c = m = None
         if self.source is not None:
             stored = self.source(ptr)
@@ -537,15 +556,21 @@ def emit_quotient(em, pl):
         h = em.normalised(h)
     em.use(h)
     dead = {n for n in em.leaves if n not in em.used}       # e.g. a selector loaded by the program and applied once per run instead
-    em.lines = [l for l in em.lines if not any(l.startswith("    const E29 %s = ld29(" % n) for n in dead)]
+    dead_raw = {"raw%d" % k for k, n in enumerate(em.leaves) if n in dead}
+    em.lines = [l for l in em.lines if not any(l.startswith("    const E29 %s = ld29(" % n) or l.startswith("    const E29 %s = R29::split<0>(raw" % n) for n in dead)
+                and not any(l.startswith("    const Fr %s = ld(" % r) for r in dead_raw)]
     em.lines.append("    st(a.h + i, R29::to_fp(%s));" % h.name)
     return h
 
 
 def kernel_text(name, pl):
     em = Emitter()
+    if PREFETCH_AHEAD:
+        dry = Emitter()
+        emit_quotient(dry, pl)
+        em.ahead = dry.leaf_ptrs
     emit_quotient(em, pl)
-    head = ["__global__ __launch_bounds__(QUOT29_THREADS) void %s(Quot29Args a) {" % name,
+    head = ["__global__ __launch_bounds__(QUOT29_THREADS, 2) void %s(Quot29Args a) {" % name,
             "    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;",
             "    const uint32_t base = i & ~a.mask;",
             "    const uint32_t inext = base | ((i + 1) & a.mask), iprev = base | ((i - 1) & a.mask);",
