@@ -35,6 +35,28 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _restrict_host_cores():
+    """--host-cores N: pin this process (and every thread it will start: lanes, witness helpers, the HIP runtime's own) to N
+    of the cores it may use, BEFORE anything touches the GPU -- what the same run costs on a host with fewer cores per GPU.
+    Under a multi-rank launch every rank takes its own block of N cores."""
+    n = None
+    for i, arg in enumerate(sys.argv):
+        if arg == "--host-cores" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif arg.startswith("--host-cores="):
+            n = int(arg.split("=", 1)[1])
+    if not n or not hasattr(os, "sched_setaffinity"):
+        return None
+    avail = sorted(os.sched_getaffinity(0))
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    block = avail[(lr * n) % max(1, len(avail)):][:n] or avail[:n]
+    os.sched_setaffinity(0, block)
+    return len(block)
+
+
+HOST_CORES_PINNED = _restrict_host_cores()
 # Proving lanes are HIP streams, and ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues: kernels of lanes that share a
 # queue run one after the other.  Measured with 48 lanes on one MI355X: 1710 proofs/s on 12 queues, 1804 on 16, 1828 on 18,
 # 1859 on 20, 1887 on 22 -- and 1544 on 24 or 28: past 22 the runtime runs out of hardware queues of its own and multiplexes.
@@ -43,7 +65,7 @@ sys.path.insert(0, ROOT)
 HW_QUEUES = int(os.environ.get("SHP_BENCH_HW_QUEUES", "22"))
 if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < HW_QUEUES or "SHP_BENCH_HW_QUEUES" in os.environ:
     os.environ["GPU_MAX_HW_QUEUES"] = str(min(HW_QUEUES, 32))
-os.environ["SHP_KEEP_HW_QUEUES"] = "1"                  # the package would raise a smaller value to 16 again
+os.environ["SHP_HW_QUEUES"] = os.environ["GPU_MAX_HW_QUEUES"]     # the library's spelling of the same explicit choice
 # the CPU baseline (OpenMP oracle) is fastest at the CPU share one GPU gets on this box: measured on the
 # MI355X host, ms per proof at 8 / 16 / 32 / 64 / 128 threads = 789 / 600 / 704 / 1001 / 1951
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 16)))
@@ -143,6 +165,12 @@ def main():
     ap.add_argument("--event-lanes", type=int, default=1, help="lanes whose kernels are timed with HIP events in the timed region")
     ap.add_argument("--verify-proofs", type=int, default=16, help="proofs of the last timed step checked with shp_verify")
     ap.add_argument("--micro", type=int, nargs="*", default=[20, 22, 24], help="log2 sizes of the standalone MSM / NTT block ([] = skip)")
+    ap.add_argument("--host-cores", type=int, default=0, help="pin the process to this many host cores before it touches the GPU "
+                                                              "(what the run costs on a host with fewer cores per GPU; 0 = all)")
+    ap.add_argument("--interpreted-steps", type=int, default=3, help="steps of the same workload with the quotient's expressions "
+                    "INTERPRETED (a circuit the library was not built with); reported beside the headline, 0 = skip")
+    ap.add_argument("--tiled-msm-bases", action="store_true", help="micro block: tile 4096 points to size instead of generating "
+                                                                   "2^log_n distinct ones on the device")
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)   # gloo path test, no GPU
     a = ap.parse_args()
 
@@ -189,7 +217,7 @@ def main():
             cores = min(cores, max(1, int(quota) // int(period)))
     except (OSError, ValueError):
         pass
-    share = cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    share = cores if HOST_CORES_PINNED else cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if share < a.lanes:
         os.environ.setdefault("SHP_BLOCKING_SYNC", "1")
 
@@ -197,20 +225,35 @@ def main():
     import torch
     shp = importlib.import_module("zkos-monorepo_amd")
     circuits = importlib.import_module("zkos-monorepo_amd.circuits")
-    ctx = shp.Context(local_rank)
+    # one rank per GPU; a rehearsal with more ranks than GPUs (two ranks on the one GPU of a test box) wraps around
+    ctx = shp.Context(local_rank % max(1, shp.device_count()))
     plan, lay = circuits.build_withdraw_plan()                 # k = 13, height 13, 12-bit range table
+    # start-up cost, outside the timed region: every rank pays it (in parallel), a restarted server pays it before its
+    # first proof.  SRS = 2^13 powers of tau + the group FFT for g_lagrange + both multiples tables; key = fixed / sigma
+    # columns, their commitments and quotient-domain values; pool = lanes x (stream + 75 MB workspace)
+    setup_s = {}
+    t_setup = time.perf_counter()
     params = shp.Params.synthetic(ctx, 13, TAU)
+    torch.cuda.synchronize()
+    setup_s["srs_and_tables"] = time.perf_counter() - t_setup
     # window width and HBM bytes of the two multiples tables the commitments gather from
     msm_tables = {}
     for label, basis in (("lagrange", shp.BASIS_LAGRANGE), ("monomial", shp.BASIS_MONOMIAL)):
         direct, c, nbytes = params.msm_info(basis)
         msm_tables[label] = {"direct": bool(direct), "window_bits": int(c), "GB": round(nbytes / 1e9, 1)}
+    t_setup = time.perf_counter()
     pk = shp.ProvingKey(ctx, params, plan)
+    torch.cuda.synchronize()
+    setup_s["keygen"] = time.perf_counter() - t_setup
+    compiled_level = pk.compiled_level()
     make_wit = lambda rnd_: b"".join(int(x).to_bytes(32, "little")
                                      for x in circuits.withdraw_witness_inputs(lay, shp.poseidon2_hash_host, rnd_))
     # the native proving pool: a.lanes lanes (HIP stream + HBM workspace each) behind one FIFO queue,
     # fed by C++ worker threads; one step = ONE shp_prove_batch call
+    t_setup = time.perf_counter()
     pool = shp.Pool(pk, a.lanes)
+    setup_s["pool"] = time.perf_counter() - t_setup
+    setup_s = {k_: round(v_, 3) for k_, v_ in setup_s.items()}
     provers = [pool.lane(i) for i in range(a.lanes)]
     if a.batch:
         # strong scaling: the SAME batch of a.batch distinct (witness, seed) pairs on every world size, this rank's
@@ -275,6 +318,11 @@ def main():
             raise SystemExit(f"bench.py: proof {jj} of the last timed step does not verify")
         verified += 1
 
+    verified_all = verified
+    if dist:
+        t = torch.tensor([verified], dtype=torch.int64)        # host tensor over gloo
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        verified_all = int(t.item())
     if rank != 0:
         if dist:
             dist.barrier()
@@ -373,12 +421,17 @@ def main():
         "config": {"workload": ("batch of %d independent 2^13 withdraw-shaped proofs sharded over the ranks" % a.batch) if a.batch else
                                "2^13 withdraw-shaped circuit plan (stand-in), KZG/SHPLONK proof, synthetic k=13 SRS",
                    "proofs_per_step": proofs_per_step_all, "proofs_per_step_rank0": per_step, "lanes": a.lanes, "k": 13,
+                   # 2: the whole numerator of the quotient is a kernel compiled into the library for THIS plan; 1: its gate
+                   # program is; 0: interpreted.  The reference, too, fixes its circuits when it is built
+                   # (/root/reference/crates/shielder_bindings/build.rs:19-48); "interpreted" below prices a circuit that was not
+                   "compiled_level": compiled_level, "host_cores_pinned": HOST_CORES_PINNED,
                    "host_cores_per_rank": share, "host_cores_visible": cores, "host_cpu_util_rank0": round(host_cpu_util, 3),
                    "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "event_lanes": a.event_lanes,
                    "msm_tables": msm_tables,
                    "blocking_sync": os.environ.get("SHP_BLOCKING_SYNC") == "1",
                    "parallelism": f"proofs sharded over {n_gpus} GPU(s), no data-path collective, gloo barrier"},
-        "verified": verified,
+        "verified": verified_all,             # proofs of the last timed step checked by shp_verify, summed over the ranks
+        "setup_s": setup_s,                   # rank 0's start-up cost (SRS + tables, keygen, pool), outside the timed region
         "p50_latency_ms": 1e3 * lat[len(lat) // 2] if lat else None,
         "latency_proofs": len(lat),
         "phase_us_p50": phase_us_p50,          # host wall time per prover phase of a lone proof (median)
@@ -398,8 +451,10 @@ def main():
         "kernel_us_per_launch_alone": {k_: 1e3 * ms_ / c_ for k_, (c_, ms_) in sorted(alone.items())},
     }
     pool.close()
+    if world == 1 and a.interpreted_steps > 0 and not a.batch:
+        out["interpreted"] = interpreted_block(shp, ctx, params, plan, a, wit_blob, seed_of, per_step, proofs_buf, lens_buf)
     if world == 1 and a.micro:
-        out["micro"] = micro_block(shp, ctx, a.micro)
+        out["micro"] = micro_block(shp, ctx, a.micro, a.tiled_msm_bases)
     if world == 1 and a.cpu_proofs > 0:
         out["cpu_baseline"] = cpu_baseline(plan, lay, a.cpu_proofs)
     print(json.dumps(out), flush=True)
@@ -408,7 +463,45 @@ def main():
         dist.destroy_process_group()
 
 
-def micro_block(shp, ctx, sizes):
+def interpreted_block(shp, ctx, params, plan, a, wit_blob, seed_of, per_step, proofs_buf, lens_buf):
+    """The same step with the quotient's expressions interpreted: what a circuit costs that was not compiled into the
+    library (keys read SHP_QUOT29 / SHP_GATE_AOT when they are generated).  Outside the headline's timed region."""
+    import torch
+    saved = {k_: os.environ.get(k_) for k_ in ("SHP_QUOT29", "SHP_GATE_AOT")}
+    os.environ["SHP_QUOT29"] = "0"
+    os.environ["SHP_GATE_AOT"] = "0"
+    try:
+        pk = shp.ProvingKey(ctx, params, plan)
+    finally:
+        for k_, v_ in saved.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
+    level = pk.compiled_level()
+    pool = shp.Pool(pk, a.lanes)
+    counter = [1 << 20]
+
+    def step():
+        seeds = b"".join(seed_of(counter[0], j) for j in range(per_step))
+        pool.prove_batch_raw(wit_blob, seeds, per_step, proofs_buf, lens_buf)
+        counter[0] += 1
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.interpreted_steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ok = all(lens_buf[i] == pk.proof_len for i in range(per_step))
+    pool.close(); pk.close()
+    return {"value": a.interpreted_steps * per_step / el, "unit": "proofs/s", "compiled_level": level, "steps": a.interpreted_steps,
+            "ms_per_step": 1e3 * el / a.interpreted_steps, "all_proofs_present": ok,
+            "note": "same plan, witnesses and lanes; gate, permutation and lookup expressions run in the generic kernels"}
+
+
+def micro_block(shp, ctx, sizes, tiled=False):
     """BASELINE.json configs[3] / [4]: one G1 MSM and one Fr NTT of 2^log_n elements, inputs resident in HBM.
     MSM: 96 N algorithmic bytes (scalar + base), point additions and Fq products per second (10 products per mixed
     addition); NTT: 64 N algorithmic bytes, 64 N x passes moved, (N/2) log2 N butterflies."""
@@ -421,8 +514,8 @@ def micro_block(shp, ctx, sizes):
         raw[:, 3] &= np.uint64((1 << 61) - 1)
         return raw
 
-    out = {"msm": [], "ntt": []}
-    small = shp.Params.synthetic(ctx, 12, 0xB105F00D)          # 4096 distinct points, tiled to size
+    out = {"msm": [], "ntt": [], "msm_bases": "4096 points tiled" if tiled else "distinct points d * tau^i * G, generated on the device"}
+    small = shp.Params.synthetic(ctx, 12, 0xB105F00D)          # 4096 distinct points tau^i G
     base = small.get_g()
     small.close()
     for lg in sizes:
@@ -444,8 +537,13 @@ def micro_block(shp, ctx, sizes):
                            "butterflies_per_s": (n / 2) * lg / (ms * 1e-3)})
         del t
         # MSM over n fixed bases (window tables built once, outside the timing)
-        bases = np.tile(base, (n // base.shape[0], 1))
-        m = shp.Msm(ctx, bases)
+        if tiled:
+            bases = np.tile(base, (n // base.shape[0], 1))
+            m = shp.Msm(ctx, bases)
+        else:
+            # 2^log_n DISTINCT affine points: the d-th multiple of each of the 4096 powers, d = 1 .. n / 4096
+            bases = shp.distinct_points(ctx, base, n // base.shape[0])
+            m = shp.Msm.from_device(ctx, bases, n)
         del bases
         sc = shp.to_device(rand_fr(n))
         m.run(sc, n, 1)

@@ -23,7 +23,12 @@
  *   - pointers named d_* are DEVICE pointers (HBM) on the current device, h_* are host
  *     pointers; `stream` is a hipStream_t passed as void* (NULL = the context's stream);
  *   - the library never falls back to a CPU implementation: without a usable gfx950
- *     device every compute entry point fails with SHP_ERR_NO_DEVICE.
+ *     device every compute entry point fails with SHP_ERR_NO_DEVICE;
+ *   - GPU_MAX_HW_QUEUES (ROCm's own: hardware queues per process, 4 by default; proving lanes that share a queue run one
+ *     after the other) is the operator's: at load time the library sets it to 16 only when it is UNSET, and never
+ *     overwrites an exported value (a smaller one earns one line on stderr, which SHP_KEEP_HW_QUEUES=1 silences).
+ *     SHP_HW_QUEUES=N (1..32) asks the library to set GPU_MAX_HW_QUEUES=N itself.  Either must be in the environment
+ *     before the process's first HIP call.
  */
 #ifndef SHIELDER_HIP_H
 #define SHIELDER_HIP_H
@@ -43,13 +48,14 @@ enum {
     SHP_ERR_FORMAT = 4,       /* malformed ptau / RawBytes / plan / non-canonical field element */
     SHP_ERR_INTERNAL = 5,
     SHP_ERR_UNSATISFIED = 6,  /* witness does not satisfy the circuit (lookup input not in table) */
-    SHP_ERR_BUSY = 7          /* proving pool queue full (the reference's task pool answers HTTP 504 there) */
+    SHP_ERR_BUSY = 7,         /* proving pool queue full (the reference's task pool answers HTTP 504 there) */
+    SHP_ERR_TIMEOUT = 8       /* a bounded wait expired (shp_pool_wait_for: the reference's run timeout, also HTTP 504) */
 };
 
 #define SHP_BASIS_MONOMIAL 0  /* Params::commit          : MSM over g          */
 #define SHP_BASIS_LAGRANGE 1  /* Params::commit_lagrange : MSM over g_lagrange */
 
-typedef struct shp_ctx shp_ctx;   /* one per (process, GPU): streams, workspaces, twiddle tables */
+typedef struct shp_ctx shp_ctx;   /* one per (process, GPU): streams, workspaces, twiddle tables; a process may hold one per GPU */
 typedef struct shp_srs shp_srs;   /* device-resident KZG SRS ("Params") */
 typedef struct shp_msm shp_msm;   /* fixed-base MSM plan over one table of bases */
 typedef struct shp_pk shp_pk;     /* device-resident proving key ("ProvingKey" + its VerifyingKey) */
@@ -60,7 +66,10 @@ typedef struct shp_pool shp_pool;     /* N proving lanes behind one bounded FIFO
 const char* shp_last_error(void);
 const char* shp_version(void);
 int32_t shp_device_count(int32_t* out);
-/* Binds the calling process to GPU `device` and builds the context (one process per GPU). */
+/* Builds the context of GPU `device`.  One process per GPU is the usual layout, but a process may hold a context for each
+ * GPU of the node (the serve front does: one listener, a pool per GPU): every entry point that takes a context, or an
+ * object made from one (SRS, MSM plan, key, lane, pool, Merkle tree), makes that context's device the calling thread's
+ * current device before it touches the GPU, and leaves it so. */
 int32_t shp_ctx_create(int32_t device, shp_ctx** out);
 int32_t shp_ctx_destroy(shp_ctx* ctx);
 int32_t shp_ctx_sync(shp_ctx* ctx);                       /* wait for the context's stream */
@@ -351,6 +360,14 @@ int32_t shp_tee_decode_request(const uint8_t* json, size_t len, uint32_t height,
 int32_t shp_tee_encode_proof_response(int32_t circuit, const uint8_t* proof, size_t proof_len,
                                       const uint8_t* instances_le32, size_t n_instances, uint8_t* out, size_t cap,
                                       size_t* out_len);
+/* The two halves of shp_tee_decode_request for the HTTP front (POST /proof of the reference's prover server,
+ * /root/reference/tee/crates/shielder-prover-server/src/handlers/mod.rs:35-41, generate_proof.rs:13-34):
+ * shp_http_decode_proof_body parses GenerateProofPayload {"payload": base64} into the payload bytes (payload_out == NULL
+ * sizes); shp_tee_decode_payload decodes those bytes -- the Payload JSON of protocol.rs:14-20 -- as the payload of a
+ * GenerateProof request.  SHP_ERR_FORMAT as above. */
+int32_t shp_http_decode_proof_body(const uint8_t* json, size_t len, uint8_t* payload_out, size_t cap, size_t* payload_len);
+int32_t shp_tee_decode_payload(const uint8_t* json, size_t len, uint32_t height, int32_t* circuit, uint8_t* witness_le32,
+                               size_t witness_cap, size_t* n_inputs);
 
 /* ---- proving pool: the "whole node" serve path ----------------------------------------
  * Replaces the reference's per-connection proving tasks behind a bounded task pool
@@ -367,6 +384,14 @@ int32_t shp_pool_lane(shp_pool* p, uint32_t index, shp_prover** lane);   /* e.g.
 int32_t shp_pool_submit(shp_pool* p, const uint8_t* witness_le32, size_t n_inputs, const uint8_t seed[32], uint64_t* ticket);
 int32_t shp_pool_wait(shp_pool* p, uint64_t ticket, uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
                       uint8_t* instances_le32, size_t instances_cap);
+/* shp_pool_wait bounded by the reference's run timeout (tokio_task_pool with_run_timeout, TEE_COMPUTE_TIMEOUT_SECS = 60,
+ * /root/reference/tee/crates/shielder-prover-server/src/main.rs:42-45, command_line_args.rs:37-40): SHP_ERR_TIMEOUT when
+ * the proof is not there after timeout_ms.  The ticket is abandoned then: a job still queued is skipped, one already on a
+ * lane finishes and is discarded. */
+int32_t shp_pool_wait_for(shp_pool* p, uint64_t ticket, uint32_t timeout_ms, uint8_t* proof_out, size_t proof_cap,
+                          size_t* proof_len, uint8_t* instances_le32, size_t instances_cap);
+/* jobs accepted and not finished (queued or on a lane): what a front that balances several pools compares */
+int32_t shp_pool_outstanding(const shp_pool* p, uint64_t* jobs);
 /* synchronous batch of `count` independent proofs over the pool's lanes: witness i at
  * witnesses_le32 + i * n_inputs * 32, seed i at seeds + 32 i, proof i at proofs_out + i * proof_stride
  * (length in proof_lens[i]), public inputs i at instances_le32 + i * instances_stride (optional).
@@ -378,32 +403,59 @@ int32_t shp_pool_stats(const shp_pool* p, uint64_t* proofs_done, uint64_t* queue
 /* the shape of the pool's key: witness inputs per proof, public inputs, proof length in bytes */
 int32_t shp_pool_info(const shp_pool* p, uint32_t* n_witness_inputs, uint32_t* n_instances, uint32_t* proof_len);
 
-/* ---- native serve loop: TCP front of the proving pools ---------------------------------
- * Server::handle_client of the reference's enclave server (/root/reference/tee/crates/shielder-prover-tee/src/
- * server.rs:69-90) over TCP: per connection a sequence of length-delimited requests (4-byte big-endian length,
- * tokio_util LengthDelimitedCodec as in tee/crates/shielder-prover-common/src/vsock.rs:69-102, at most 8 MiB),
- * Ping -> Pong, TeePublicKey -> empty key and attestation (ECIES / attestation are out of scope), GenerateProof ->
- * EncryptedProof from the pool registered for the payload's CircuitType; a malformed frame, an unknown circuit type
- * or a failed proof ends the connection, as any error does in the reference (server.rs:70-73).  Frames are decoded
- * and answered by shp_tee_decode_request / shp_tee_encode_proof_response, one thread per connection (at most 1024
- * connections at a time: further peers are closed at once and counted as failed); blinding
- * seeds come from getrandom(2) (the reference: rand::thread_rng(), circuits/withdraw.rs:112).
- * pools[i] serves circuits[i] (SHP_TEE_NEW_ACCOUNT / _DEPOSIT / _WITHDRAW, each at most once; n_pools may be 0: the
- * server then answers Ping and TeePublicKey only); merkle_height as for shp_tee_decode_request; bind_addr a dotted
- * IPv4 address (NULL = 127.0.0.1); port 0 = any free port (shp_server_port reports it).  The pools must outlive
- * the server.  shp_server_stop closes the listener and every connection, joins the threads and frees the server. */
+/* ---- native serve loop: one TCP front for the proving pools of a whole node -------------
+ * Two fronts of the reference on one listener, told apart by a connection's first bytes:
+ *  - Server::handle_client of the enclave server (/root/reference/tee/crates/shielder-prover-tee/src/server.rs:69-90):
+ *    per connection a sequence of length-delimited requests (4-byte big-endian length, tokio_util LengthDelimitedCodec
+ *    as in tee/crates/shielder-prover-common/src/vsock.rs:69-102, at most 8 MiB), Ping -> Pong, TeePublicKey -> empty
+ *    key and attestation (ECIES / attestation are out of scope), GenerateProof -> EncryptedProof; a malformed frame, an
+ *    unknown circuit type, a failed proof or an expired timeout ends the connection, as any error does in the
+ *    reference (server.rs:70-73);
+ *  - the host-side HTTP server (/root/reference/tee/crates/shielder-prover-server/src/main.rs:47-59): GET /health,
+ *    GET /public_key, POST /proof with {"payload": base64 of the Payload JSON} -> the Response as JSON; 504 "Cannot
+ *    schedule more tasks" when no pool has a free queue slot within the spawn timeout or the proof does not finish
+ *    within the run timeout (main.rs:42-45, error.rs:30-34), 500 for a refused payload or a failed proof
+ *    (error.rs:35-38), 413 above max_http_body (DefaultBodyLimit, main.rs:57), permissive CORS (main.rs:58).
+ * pools[i] serves circuits[i] (SHP_TEE_NEW_ACCOUNT / _DEPOSIT / _WITHDRAW).  A circuit type may have SEVERAL pools (at
+ * most 64 in all) -- one per GPU of the node, each created from a key on its own context -- with keys of the same shape:
+ * every request goes to the pool with the fewest unfinished jobs (shp_pool_outstanding), the next one when that queue is
+ * full.  n_pools may be 0: the server then answers Ping / health and the public key only.  merkle_height as for
+ * shp_tee_decode_request; bind_addr a dotted IPv4 address (NULL = 127.0.0.1); port 0 = any free port (shp_server_port
+ * reports it).  One thread per connection, at most max_connections at a time (further peers are closed at once and
+ * counted as failed); blinding seeds come from getrandom(2) (the reference: rand::thread_rng(), circuits/withdraw.rs:112).
+ * The pools must outlive the server.  shp_server_stop closes the listener and every connection, joins the threads
+ * (a request that is being proved is waited for) and frees the server. */
 typedef struct shp_server shp_server;
+/* 0 in any field = its default.  struct_size = sizeof(shp_server_options) of the caller's header. */
+typedef struct shp_server_options {
+    uint32_t struct_size;
+    uint32_t spawn_timeout_ms;   /* wait for a free queue slot: 5000 (TASK_POOL_TIMEOUT_SECS, command_line_args.rs:33-35) */
+    uint32_t run_timeout_ms;     /* wait for the proof: 60000 (TEE_COMPUTE_TIMEOUT_SECS, command_line_args.rs:37-40) */
+    uint32_t recv_timeout_ms;    /* a frame or HTTP request, once begun, must be complete within: 5000; also the send timeout */
+    uint32_t idle_timeout_ms;    /* a connection may stay silent between requests for: 60000 */
+    uint32_t max_connections;    /* 1024 */
+    uint32_t max_http_body;      /* 102400 (MAXIMUM_REQUEST_SIZE, command_line_args.rs:30-32) */
+} shp_server_options;
 int32_t shp_server_start(shp_pool* const* pools, const int32_t* circuits, uint32_t n_pools, uint32_t merkle_height,
-                         const char* bind_addr, uint16_t port, shp_server** out);
+                         const char* bind_addr, uint16_t port, shp_server** out);      /* default options */
+int32_t shp_server_start_ex(shp_pool* const* pools, const int32_t* circuits, uint32_t n_pools, uint32_t merkle_height,
+                            const char* bind_addr, uint16_t port, const shp_server_options* options, shp_server** out);
 int32_t shp_server_port(const shp_server* s, uint16_t* port);
-/* proofs answered, connections ended by an error, connections accepted */
+/* proofs answered, requests or connections ended by an error (timeouts included), connections accepted */
 int32_t shp_server_stats(const shp_server* s, uint64_t* served, uint64_t* failed, uint64_t* connections);
+/* requests that found every queue full for the spawn timeout, proofs abandoned at the run timeout, frames or HTTP
+ * requests that stalled half-sent for the receive timeout */
+int32_t shp_server_timeouts(const shp_server* s, uint64_t* spawn, uint64_t* run, uint64_t* receive);
 int32_t shp_server_stop(shp_server* s);
 
 /* ---- diagnostics ------------------------------------------------------------------- */
 /* sustained Fr Montgomery products per second with every CU busy: the integer-ALU ceiling that
  * bounds MSM and NTT on this part: a 254-bit Montgomery product is ~300 32-bit instructions and HBM is never the limit */
 int32_t shp_diag_fr_mul_rate(shp_ctx* ctx, uint32_t iters, double* muls_per_sec);
+/* Generator of large sets of DISTINCT affine points for stand-alone MSM measurements, on the device: out[r * multiples +
+ * d - 1] = d * bases[r] for d = 1 .. multiples (a power of two in [64, 65536]; n_rows * multiples <= 2^26; d_bases and d_out
+ * in HBM, 64 B per point).  The kernel is the one that builds an SRS's multiples tables. */
+int32_t shp_diag_multiples(shp_ctx* ctx, const void* d_bases, size_t n_rows, uint32_t multiples, void* d_out);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ on-chain hasher, /root/reference/poseidon2-solidity/generate_t8.py (+ utils.py),
 the generator, takes the Yul text it emits and executes it with the small Yul evaluator below
 (EVM word semantics: add wraps mod 2^256, addmod/mulmod as the EVM defines them), then writes
 inputs and outputs to tests/golden/poseidon2_t8.json.  Only the vectors are committed; nothing
-of the reference travels.  Run in the build container:  python3 tools/gen_golden_poseidon2.py
+of the reference travels.  Run in the build container:  python3 oracle/tools/gen_golden_poseidon2.py
 """
 import json, os, random, re, sys
 
@@ -130,7 +130,7 @@ def main():
     cases = [list(range(1, 8)), [0] * 7, [g.F - 1] * 7, [1, 0, 0, 0, 0, 0, 0]]
     cases += [[rnd.randrange(g.F) for _ in range(7)] for _ in range(12)]
     vec = [{"inputs": ["0x%064x" % x for x in c], "hash": "0x%064x" % reference_hash(c)} for c in cases]
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "poseidon2_t8.json")
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "poseidon2_t8.json")
     with open(out, "w") as f:
         json.dump({"source": "executed Yul emitted by /root/reference/poseidon2-solidity/generate_t8.py",
                    "field_modulus": "0x%064x" % g.F, "vectors": vec}, f, indent=1)

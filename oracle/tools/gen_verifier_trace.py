@@ -20,7 +20,7 @@ container only:
      tests/golden/verifier_trace.json.
 
 Only those vectors are committed; nothing of the reference travels.  tests/test_verifier_trace.py makes oracle/plonk.py:verify
-and the library's shp_verify reproduce them.     python3 tools/gen_verifier_trace.py
+and the library's shp_verify reproduce them.     python3 oracle/tools/gen_verifier_trace.py
 """
 import importlib
 import json
@@ -30,7 +30,7 @@ import re
 import sys
 
 sys.dont_write_bytecode = True
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_NUM_THREADS", "8")
 TEMPLATE = "/root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol"
@@ -996,7 +996,7 @@ def main():
     out = os.path.join(ROOT, "tests", "golden", "verifier_trace.json")
     with open(out, "w") as f:
         json.dump({"source": "Yul of /root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol rendered for the plan and executed "
-                             "by tools/gen_verifier_trace.py; words are EVM memory words of the contract after the run",
+                             "by oracle/tools/gen_verifier_trace.py; words are EVM memory words of the contract after the run",
                    "trace_words": TRACE_WORDS, "cases": cases}, f, indent=1)
     print("wrote", out)
 

@@ -115,3 +115,34 @@ def test_cpp_prover_server_answers_a_withdraw_request(oracle, tmp_path):
         assert inst == list(oinst)
         assert PL.verify(opk, proof, inst, tau=TAU)
     assert resps[0]["EncryptedProof"]["proof"] != resps[1]["EncryptedProof"]["proof"]      # fresh randomness per request
+
+
+@pytest.mark.parametrize("batch", [0, 64])
+def test_bench_two_ranks_with_real_pools(batch):
+    """bench.py's multi-rank path with REAL proving pools: two ranks (one process each, gloo barrier, no data-path collective),
+    both on the one GPU of a test box -- the launch the driver makes on an 8-GPU node, at world size 2.  Weak scaling (every
+    rank proves lanes x proofs-per-lane per step) and BASELINE config 3's shape (--batch: one fixed batch cut into contiguous
+    shards).  One JSON line from rank 0, the proofs of every rank's last step verified and counted over gloo."""
+    b = sys.modules.get("zkos-monorepo_amd.binding")
+    if b is not None and b.Context.created:
+        pytest.skip("this process has already initialised the GPU: it must not start another program")
+    env = dict(os.environ, SHP_MSM_TABLE_GB="20")                   # two replicas of the tables on one GPU
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--lanes", "8",
+           "--proofs-per-lane", "4", "--latency-proofs", "8", "--verify-proofs", "6", "--cpu-proofs", "0", "--micro"]
+    if batch:
+        cmd += ["--batch", str(batch)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["unit"] == "proofs/s" and j["value"] > 0
+    if batch:
+        assert j["scaling"] == "strong" and j["config"]["proofs_per_step"] == batch and j["config"]["proofs_per_step_rank0"] == batch // 2
+    else:
+        assert j["scaling"] == "weak" and j["config"]["proofs_per_step"] == 2 * 8 * 4
+    assert j["verified"] == 12                                      # 6 on each rank, summed over gloo
+    assert abs(j["value"] - j["config"]["proofs_per_step"] * 2 / (2 * j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+    assert j["config"]["compiled_level"] == 2 and "micro" not in j and "cpu_baseline" not in j
+    assert j["setup_s"]["srs_and_tables"] > 0 and j["p50_latency_ms"] > 0

@@ -114,6 +114,13 @@ def test_injected_transcript_repr(shp, oracle, gpu_ctx):
     assert plain.vk_digest() != pk.vk_digest() and not plain.verify(proof, inst)
     pk2 = shp.ProvingKey.load(gpu_ctx, params, pk.save())
     assert pk2.vk_digest() == pk.vk_digest() and pk2.verify(proof, inst)
+    # the saved key also carries the library's own digest over plan and commitments: a flipped byte in a commitment (or in
+    # the plan) does not load, although the injected vk_digest is taken from the file as it is
+    blob = bytearray(pk.save())
+    blob[-64 - 40] ^= 1                                               # inside the last permutation commitment
+    with pytest.raises(shp.ShpError) as e:
+        shp.ProvingKey.load(gpu_ctx, params, bytes(blob))
+    assert e.value.code == shp.SHP_ERR_FORMAT
     with pytest.raises(shp.ShpError) as e:
         shp.ProvingKey(gpu_ctx, params, plan.data, transcript_repr=R)
     assert e.value.code == shp.SHP_ERR_FORMAT
@@ -123,7 +130,7 @@ def test_injected_transcript_repr(shp, oracle, gpu_ctx):
 def test_saved_key_is_bound_to_its_srs(shp, oracle, gpu_ctx):
     PL, C, plan, lay, osrs, opk, params, pk, H = small_setup(shp, oracle, gpu_ctx)
     blob = pk.save()
-    assert blob[:8] == b"SHPK0002"
+    assert blob[:8] == b"SHPK0003"
     other = shp.Params.synthetic(gpu_ctx, plan.k, TAU + 1)
     with pytest.raises(shp.ShpError) as e:
         shp.ProvingKey.load(gpu_ctx, other, blob)

@@ -210,7 +210,7 @@ def test_pk_save_load_roundtrip(shp, oracle, gpu_ctx):
     whose parts were altered does not load"""
     PL, C, plan, lay, osrs, opk, params, pk = setup(shp, oracle, gpu_ctx, True)
     blob = pk.save()
-    assert blob[:8] == b"SHPK0002"
+    assert blob[:8] == b"SHPK0003"
     pk2 = shp.ProvingKey.load(gpu_ctx, params, blob)
     assert pk2.vk_digest() == pk.vk_digest() and (pk2.k, pk2.n_inputs, pk2.proof_len) == (pk.k, pk.n_inputs, pk.proof_len)
     H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]

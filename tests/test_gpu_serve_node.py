@@ -1,0 +1,188 @@
+"""GPU: the node-level serve front -- several pools of one circuit type behind one listener, the reference's request
+limits (spawn and run timeouts of /root/reference/tee/crates/shielder-prover-server/src/main.rs:42-45, answered 504 as in
+error.rs:30-34), its HTTP routes (main.rs:47-59), and the serve-style key set-up that shares the full SRS's tables."""
+import base64
+import concurrent.futures
+import http.client
+import importlib
+import json
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+TAU = 0x1234567890ABCDEF1234567890ABCDEF55
+GIB = 1 << 30
+
+
+def small_setup(shp, oracle, ctx):
+    from oracle import plonk as PL
+    C = importlib.import_module("zkos-monorepo_amd.circuits")
+    plan_bytes, lay = C.build_withdraw_plan(k=9, height=1, range_bits=4, range_chunks=8)
+    plan = PL.Plan(plan_bytes)
+    osrs = oracle.srs_synthetic(plan.k, TAU)
+    opk = PL.keygen(plan, osrs)
+    params = shp.Params.synthetic(ctx, plan.k, TAU)
+    pk = shp.ProvingKey(ctx, params, plan_bytes)
+    return PL, C, plan, lay, opk, params, pk
+
+
+def http_body(C, lay, oracle, seed):
+    """(POST /proof body, witness) of one withdraw request in the reference's encodings"""
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    wit = C.withdraw_witness_inputs(lay, H, random.Random(seed), 2**31 + 1, 2**20 + 2)
+    le = lambda x: list(int(x).to_bytes(32, "little"))
+    h = lay.height
+    inputs = {"id": le(wit[lay.ID]), "nullifier_old": le(wit[lay.NULLIFIER_OLD]), "account_balance_old": le(wit[lay.BALANCE_OLD]),
+              "token_address": le(wit[lay.TOKEN]), "path": [b for x in wit[4:4 + 7 * h] for b in le(x)], "value": le(wit[lay.VALUE]),
+              "nullifier_new": le(wit[lay.NULLIFIER_NEW]), "commitment": le(wit[lay.COMMITMENT]), "mac_salt": le(wit[lay.MAC_SALT])}
+    payload = json.dumps({"circuit_type": "Withdraw", "user_public_key": [], "circuit_inputs": list(json.dumps(inputs).encode())}).encode()
+    return json.dumps({"payload": base64.b64encode(payload).decode()}).encode(), wit
+
+
+def post(port, body, n=1):
+    """n POST /proof requests on one keep-alive connection -> [(status, body)]"""
+    c = http.client.HTTPConnection("127.0.0.1", port, timeout=60)
+    out = []
+    for _ in range(n):
+        c.request("POST", "/proof", body=body, headers={"Content-Type": "application/json"})
+        r = c.getresponse()
+        out.append((r.status, r.read()))
+    c.close()
+    return out
+
+
+def test_two_pools_of_one_circuit_share_the_requests(shp, oracle, gpu_ctx):
+    """two contexts in one process (the node-level layout: one per GPU; here both on device 0), a key and a pool on each,
+    ONE listener: requests over HTTP and over the enclave framing are spread over both pools, and every proof verifies
+    with the public inputs the oracle computes for the witness"""
+    S = importlib.import_module("zkos-monorepo_amd.serve")
+    PL, C, plan, lay, opk, params, pk = small_setup(shp, oracle, gpu_ctx)
+    ctx2 = shp.Context(0)
+    params2 = shp.Params.synthetic(ctx2, plan.k, TAU)
+    pk2 = shp.ProvingKey(ctx2, params2, pk.plan())
+    pools = [shp.Pool(pk, 2), shp.Pool(pk2, 2)]
+    srv = shp.NativeServer({"Withdraw": pools}, lay.height)
+    try:
+        body, wit = http_body(C, lay, oracle, 31)
+        _, oinst = PL.synthesize(plan, wit)
+        with concurrent.futures.ThreadPoolExecutor(8) as ex:
+            results = [r for rs in ex.map(lambda _: post(srv.port, body, 6), range(8)) for r in rs]
+        assert len(results) == 48 and all(st == 200 for st, _ in results)
+        proofs = set()
+        for _, data in results:
+            r = json.loads(data)["EncryptedProof"]
+            proof = base64.b64decode(r["proof"])
+            pub = json.loads(base64.b64decode(r["pub_inputs"]))
+            inst = [int.from_bytes(bytes(pub[f]), "little") for f in S.WITHDRAW_PUB_FIELDS]
+            assert inst == list(oinst)
+            assert pk.verify(proof, inst)
+            proofs.add(proof)
+        assert len(proofs) == 48                                   # fresh randomness per request
+        assert PL.verify(opk, next(iter(proofs)), list(oinst), tau=TAU)
+        done = [p.stats()[0] for p in pools]
+        assert sum(done) == 48 and min(done) >= 8, done            # both pools took a real share
+        assert [p.outstanding() for p in pools] == [0, 0]
+        assert srv.stats()[0] == 48 and srv.timeouts() == (0, 0, 0)
+    finally:
+        srv.close()
+        for p in pools:
+            p.close()
+        pk2.close(); params2.close(); ctx2.close()
+        pk.close(); params.close()
+
+
+def test_spawn_and_run_timeouts_answer_504(shp, oracle, gpu_ctx):
+    """a queue that stays full for the spawn timeout and a proof that outlasts the run timeout are answered 504 "Cannot
+    schedule more tasks" (error.rs:30-34) instead of being waited out; the pool and the server keep serving"""
+    PL, C, plan, lay, opk, params, pk = small_setup(shp, oracle, gpu_ctx)
+    body, wit = http_body(C, lay, oracle, 32)
+    # one lane, one queue slot, 24 concurrent requests, 3 ms to find a slot: most requests cannot
+    pool = shp.Pool(pk, 1, queue_cap=1)
+    srv = shp.NativeServer({"Withdraw": pool}, lay.height, spawn_timeout_ms=3)
+    try:
+        with concurrent.futures.ThreadPoolExecutor(24) as ex:
+            results = [r for rs in ex.map(lambda _: post(srv.port, body, 1), range(24)) for r in rs]
+        ok = [d for st, d in results if st == 200]
+        late = [d for st, d in results if st == 504]
+        assert len(ok) + len(late) == 24 and ok and late, [st for st, _ in results]
+        assert all(b"Cannot schedule more tasks" in d for d in late)
+        spawn, run, recv = srv.timeouts()
+        assert spawn == len(late) and run == 0 and recv == 0
+        assert post(srv.port, body, 1)[0][0] == 200               # still serving
+    finally:
+        srv.close()
+        pool.close()
+    # one lane, room in the queue, 1 ms for a proof: requests queued behind others outlast it and are abandoned
+    pool = shp.Pool(pk, 1, queue_cap=64)
+    srv = shp.NativeServer({"Withdraw": pool}, lay.height, run_timeout_ms=1)
+    try:
+        with concurrent.futures.ThreadPoolExecutor(24) as ex:
+            results = [r for rs in ex.map(lambda _: post(srv.port, body, 1), range(24)) for r in rs]
+        late = [d for st, d in results if st == 504]
+        assert late and all(st in (200, 504) for st, _ in results)
+        assert srv.timeouts()[1] == len(late)
+    finally:
+        srv.close()
+        pool.close()                                               # drains: abandoned jobs still queued are skipped
+    # the bounded wait itself
+    pool = shp.Pool(pk, 1)
+    wit_bytes = b"".join(int(x).to_bytes(32, "little") for x in wit)
+    t = pool.submit(wit_bytes, bytes(32))
+    proof, inst = pool.wait_for(t, 30000)
+    assert pk.verify(proof, inst)
+    tickets = [pool.submit(wit_bytes, bytes([i + 1]) * 32) for i in range(12)]
+    with pytest.raises(shp.ShpError) as e:
+        pool.wait_for(tickets[-1], 1)
+    assert e.value.code == shp.SHP_ERR_TIMEOUT
+    with pytest.raises(shp.ShpError):
+        pool.wait(tickets[-1])                                     # the ticket is gone
+    for t in tickets[:-1]:
+        proof, inst = pool.wait(t)
+        assert pk.verify(proof, inst)
+    pool.close(); pk.close(); params.close()
+
+
+def test_serve_style_setup_shares_the_full_srs_tables(shp, oracle, gpu_ctx):
+    """serve.py's key set-up (generate_keys_with_min_k for every circuit over one full SRS, as the reference's build step
+    does, crates/shielder_bindings/build.rs:19-60): the 2^13 circuits prove over the full SRS's own multiples tables --
+    the downsize to the same k shares them -- so three circuit types cost one 228 GB table pair plus NewAccount's
+    smaller one, not three pairs squeezed into what the first left over"""
+    import torch
+    S = importlib.import_module("zkos-monorepo_amd.serve")
+    C = importlib.import_module("zkos-monorepo_amd.circuits")
+    gpu_ctx.set_hbm_limit(0)
+    free0, total = torch.cuda.mem_get_info(0)
+    params = shp.Params.synthetic(gpu_ctx, 13, TAU)
+    full = [params.msm_info(b) for b in (shp.BASIS_LAGRANGE, shp.BASIS_MONOMIAL)]
+    assert full[0][0] and full[0][1] == 15 and full[1][0] and full[1][1] == 14, full
+    used_by_full = free0 - torch.cuda.mem_get_info(0)[0]
+    backends = S.build_backends(shp, C, gpu_ctx, params, lanes=2)
+    try:
+        for ctype in ("Withdraw", "Deposit"):
+            srs = backends[ctype].pool.pk.params
+            assert srs.k == 13
+            assert [srs.msm_info(b) for b in (shp.BASIS_LAGRANGE, shp.BASIS_MONOMIAL)] == full, ctype
+        na = backends["NewAccount"].pool.pk.params
+        assert na.k == 12
+        for b in (shp.BASIS_LAGRANGE, shp.BASIS_MONOMIAL):
+            direct, c, _ = na.msm_info(b)
+            assert direct and c >= 12, (b, direct, c)
+        used_by_all = free0 - torch.cuda.mem_get_info(0)[0]
+        assert used_by_all - used_by_full < 60 * GIB, (used_by_full / GIB, used_by_all / GIB)
+        # the shared tables outlive the SRS they were built for
+        params.close()
+        H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+        _, lay = C.build_withdraw_plan()
+        wit = C.withdraw_witness_inputs(lay, H, random.Random(5))
+        wit_bytes = b"".join(int(x).to_bytes(32, "little") for x in wit)
+        for ctype in ("Withdraw",):
+            pool = backends[ctype].pool
+            proof, inst = pool.wait(pool.submit(wit_bytes, bytes(32)))
+            assert pool.pk.verify(proof, inst)
+    finally:
+        for b in backends.values():
+            b.pool.close()
+            b.pool.pk.close()
+            b.pool.pk.params.close()
+        params.close()

@@ -2,7 +2,7 @@
 
 tests/golden/verifier_trace.json holds what the contract rendered from
 /root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol computed when its Yul was executed on proofs of the CPU
-oracle (tools/gen_verifier_trace.py, run in the build container): the accept / reject answer and the contract's named
+oracle (oracle/tools/gen_verifier_trace.py, run in the build container): the accept / reject answer and the contract's named
 memory words -- every Fiat-Shamir challenge, x^n, l_last, l_blind, l_0, the instance evaluation, the quotient evaluation
 and commitment, the SHPLONK scalar and both pairing inputs.  Here oracle/plonk.py:verify (CPU) and shp_verify (the
 library's native verifier) must reproduce them word for word, and the oracle must still produce the very proof bytes the

@@ -25,7 +25,7 @@ def _both(shp, ctx, a, log_n, batch, inverse):
 
 
 def test_noalloc_ntt_equals_ntt_two_calls_second_smaller(shp, oracle, gpu_ctx):
-    # first call: 2^20 elements, three passes (fills the whole static array)
+    # first call: 2^20 elements, two passes of 1024-element tiles (fills the whole static array)
     a = rand_fr(oracle, 1 << 20, 9001)
     got, want = _both(shp, gpu_ctx, a, 20, 1, False)
     assert np.array_equal(got, want), "2^20 forward"
@@ -36,7 +36,8 @@ def test_noalloc_ntt_equals_ntt_two_calls_second_smaller(shp, oracle, gpu_ctx):
     assert np.array_equal(got, want), "3 x 2^14 forward after the large call"
     got, want = _both(shp, gpu_ctx, b, 14, 3, True)
     assert np.array_equal(got, want), "3 x 2^14 inverse"
-    # every pass structure once: single pass (no ping-pong), two passes, three passes; inverse undoes forward
+    # every pass structure the entry point has (log_n <= 20): a single pass (no ping-pong) and two passes, with both tile
+    # sizes; inverse undoes forward
     for log_n, batch in ((1, 5), (5, 2), (11, 4), (12, 1), (13, 7), (18, 2), (19, 2), (20, 1)):
         c = rand_fr(oracle, batch << log_n, 9100 + log_n)
         got, want = _both(shp, gpu_ctx, c, log_n, batch, False)

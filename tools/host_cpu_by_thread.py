@@ -5,7 +5,6 @@ CPU time of every thread of the process (from /proc/self/task), busiest first.
 import argparse, importlib, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "22")
 
 
 def thread_times():
@@ -27,6 +26,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=4.0)
     a = ap.parse_args()
     shp = importlib.import_module("zkos-monorepo_amd")
+    shp.set_hw_queues(int(os.environ.get("SHP_BENCH_HW_QUEUES", "22")))
     circuits = importlib.import_module("zkos-monorepo_amd.circuits")
     shp.prefer_sleeping_waits(a.lanes)
     ctx = shp.Context(0)

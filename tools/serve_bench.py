@@ -61,6 +61,7 @@ def main():
             procs.append((pr, here))
             first += share[r]
     shp = importlib.import_module("zkos-monorepo_amd")
+    shp.set_hw_queues(int(os.environ.get("SHP_BENCH_HW_QUEUES", "22")))     # an explicit choice for this benchmark process
     circuits = importlib.import_module("zkos-monorepo_amd.circuits")
     S = importlib.import_module("zkos-monorepo_amd.serve")
     shp.prefer_sleeping_waits(a.lanes)

@@ -18,7 +18,7 @@ Q_MOD = 218882428718392752222464057452572750886963111572978236626890378946452262
 
 SHP_OK = 0
 (SHP_ERR_INVALID_ARG, SHP_ERR_NO_DEVICE, SHP_ERR_HIP, SHP_ERR_FORMAT, SHP_ERR_INTERNAL, SHP_ERR_UNSATISFIED,
- SHP_ERR_BUSY) = range(1, 8)
+ SHP_ERR_BUSY, SHP_ERR_TIMEOUT) = range(1, 9)
 BASIS_MONOMIAL, BASIS_LAGRANGE = 0, 1
 
 
@@ -42,6 +42,21 @@ def build(force=False):
 _lib = None
 
 
+def set_hw_queues(n: int, quiet=False) -> int:
+    """An explicit, logged choice of GPU_MAX_HW_QUEUES for this process (benchmarks, the serve front): call before
+    anything touches the GPU.  Returns the value in force; a process whose HIP runtime is already up keeps its own."""
+    if _lib is not None:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
+    n = max(1, min(int(n), 32))
+    before = os.environ.get("GPU_MAX_HW_QUEUES")
+    os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+    os.environ["SHP_HW_QUEUES"] = str(n)
+    if not quiet and before != str(n):
+        import sys
+        print(f"[shielder_hip] GPU_MAX_HW_QUEUES {before or 'unset'} -> {n} for this process", file=sys.stderr, flush=True)
+    return n
+
+
 def lib():
     """The HIP library; raises if it has not been built (there is no CPU fallback)."""
     global _lib
@@ -53,16 +68,14 @@ def lib():
         # importing it FIRST makes libshielder_hip resolve its hip* symbols to that same runtime
         # instance, so stream handles and device pointers are interchangeable between the two.
         # Proving lanes are HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (HIP's default
-        # is 4, and hosts export it), and kernels of streams that share a queue run one after the other (measured,
-        # 16 lanes: 1149 proofs/s on 4 queues, 1400 on 16).  Must be in the environment before the HIP runtime
-        # initialises, which torch's import below may do; SHP_KEEP_HW_QUEUES=1 leaves the environment alone.
-        if os.environ.get("SHP_KEEP_HW_QUEUES") != "1":
-            try:
-                cur = int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
-            except ValueError:
-                cur = 0
-            if cur < 16:
-                os.environ["GPU_MAX_HW_QUEUES"] = "16"
+        # is 4), and kernels of streams that share a queue run one after the other (measured, 16 lanes: 1149
+        # proofs/s on 4 queues, 1400 on 16).  The value must be in the environment before the HIP runtime
+        # initialises, which torch's import below may do.  Like the library itself, this only fills in a default
+        # when the variable is unset; a program that wants more says so with set_hw_queues() before its first call.
+        if "SHP_HW_QUEUES" in os.environ:
+            os.environ["GPU_MAX_HW_QUEUES"] = os.environ["SHP_HW_QUEUES"]
+        elif not os.environ.get("GPU_MAX_HW_QUEUES"):
+            os.environ["GPU_MAX_HW_QUEUES"] = "16"
         import torch  # noqa: F401
         _lib = C.CDLL(_SO)
         _lib.shp_last_error.restype = C.c_char_p
@@ -107,6 +120,12 @@ def to_device(arr):
 
 def to_host(t):
     return t.detach().cpu().numpy().view(np.uint64)
+
+
+def device_count() -> int:
+    n = C.c_int32()
+    _check(lib().shp_device_count(C.byref(n)))
+    return n.value
 
 
 class Context:
@@ -218,6 +237,17 @@ class Msm:
         if self.h:
             lib().shp_msm_destroy(self.h)
             self.h = C.c_void_p()
+
+
+def distinct_points(ctx: Context, bases, multiples: int):
+    """shp_diag_multiples: (rows, 8) uint64 affine points -> CUDA tensor of rows * multiples DISTINCT affine points
+    d * bases[r], d = 1 .. multiples (synthetic inputs of the stand-alone MSM measurements, generated on the device)"""
+    import torch
+    b = to_device(np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8))
+    rows = b.shape[0]
+    out = torch.empty((rows * multiples, 8), dtype=torch.int64, device=b.device)
+    _check(lib().shp_diag_multiples(ctx.h, _vp(b.data_ptr()), C.c_size_t(rows), C.c_uint32(multiples), _vp(out.data_ptr())))
+    return out
 
 
 class Params:
@@ -635,6 +665,21 @@ class Pool:
                                    C.c_size_t(len(inst.raw))))
         return proof.raw[:plen.value], [int.from_bytes(inst.raw[32 * i:32 * i + 32], "little") for i in range(self.pk.n_instances)]
 
+    def wait_for(self, ticket: int, timeout_ms: int):
+        """wait bounded by the reference's run timeout: ShpError(SHP_ERR_TIMEOUT) abandons the ticket"""
+        proof = C.create_string_buffer(self.pk.proof_len)
+        plen = C.c_size_t()
+        inst = C.create_string_buffer(32 * self.pk.n_instances)
+        _check(lib().shp_pool_wait_for(self.h, C.c_uint64(ticket), C.c_uint32(timeout_ms), proof, C.c_size_t(self.pk.proof_len),
+                                       C.byref(plen), inst, C.c_size_t(len(inst.raw))))
+        return proof.raw[:plen.value], [int.from_bytes(inst.raw[32 * i:32 * i + 32], "little") for i in range(self.pk.n_instances)]
+
+    def outstanding(self) -> int:
+        """jobs accepted and not finished (queued or on a lane)"""
+        n = C.c_uint64()
+        _check(lib().shp_pool_outstanding(self.h, C.byref(n)))
+        return n.value
+
     def prove_batch(self, wits: bytes, seeds: bytes, count: int):
         """count proofs: wits = count witnesses back to back, seeds = count x 32 bytes -> [(proof, instances)]"""
         n_in = len(wits) // 32 // count
@@ -714,19 +759,49 @@ def prefer_sleeping_waits(lanes: int) -> None:
         os.environ.setdefault("SHP_BLOCKING_SYNC", "1")
 
 
+def http_decode_proof_body(body: bytes) -> bytes:
+    """GenerateProofPayload {"payload": base64} of the reference's POST /proof -> the payload bytes"""
+    n = C.c_size_t()
+    _check(lib().shp_http_decode_proof_body(C.c_char_p(body), C.c_size_t(len(body)), None, C.c_size_t(0), C.byref(n)))
+    out = C.create_string_buffer(max(1, n.value))
+    _check(lib().shp_http_decode_proof_body(C.c_char_p(body), C.c_size_t(len(body)), out, C.c_size_t(n.value), C.byref(n)))
+    return out.raw[:n.value]
+
+
+def tee_decode_payload(payload: bytes, height: int):
+    """the Payload JSON of a GenerateProof request -> (circuit name, witness bytes)"""
+    circuit, n = C.c_int32(), C.c_size_t()
+    cap = 16 * 32 + 32 * 7 * height
+    wit = C.create_string_buffer(cap)
+    _check(lib().shp_tee_decode_payload(C.c_char_p(payload), C.c_size_t(len(payload)), C.c_uint32(height), C.byref(circuit), wit,
+                                        C.c_size_t(cap), C.byref(n)))
+    return TEE_CIRCUITS[circuit.value], wit.raw[:32 * n.value]
+
+
+class ServerOptions(C.Structure):
+    """shp_server_options: 0 in a field = its default"""
+    _fields_ = [("struct_size", C.c_uint32), ("spawn_timeout_ms", C.c_uint32), ("run_timeout_ms", C.c_uint32),
+                ("recv_timeout_ms", C.c_uint32), ("idle_timeout_ms", C.c_uint32), ("max_connections", C.c_uint32),
+                ("max_http_body", C.c_uint32)]
+
+
 class NativeServer:
     """The library's own TCP front of the proving pools (shp_server, csrc/server.hip): the request loop of the reference's
-    enclave server (/root/reference/tee/crates/shielder-prover-tee/src/server.rs:69-90) without an interpreter in the
-    request path.  pools: {circuit type name: Pool}; may be empty (Ping / TeePublicKey only)."""
+    enclave server (/root/reference/tee/crates/shielder-prover-tee/src/server.rs:69-90) and the HTTP front of its prover
+    server (tee/crates/shielder-prover-server/src/main.rs:47-59) on one listener, without an interpreter in the request
+    path.  pools: {circuit type name: Pool or [Pool, ...]} -- several pools of one type (one per GPU) share its requests,
+    least loaded first; may be empty (Ping / TeePublicKey only).  options: spawn_timeout_ms, run_timeout_ms,
+    recv_timeout_ms, idle_timeout_ms, max_connections, max_http_body."""
 
-    def __init__(self, pools: dict, height: int, host: str = "127.0.0.1", port: int = 0):
-        names = list(pools)
-        arr = (C.c_void_p * max(1, len(names)))(*[pools[n].h for n in names])
-        kinds = (C.c_int32 * max(1, len(names)))(*[TEE_CIRCUITS.index(n) for n in names])
+    def __init__(self, pools: dict, height: int, host: str = "127.0.0.1", port: int = 0, **options):
+        flat = [(n, p) for n, ps in pools.items() for p in (ps if isinstance(ps, (list, tuple)) else [ps])]
+        arr = (C.c_void_p * max(1, len(flat)))(*[p.h for _, p in flat])
+        kinds = (C.c_int32 * max(1, len(flat)))(*[TEE_CIRCUITS.index(n) for n, _ in flat])
         self.pools = pools                               # the pools must outlive the server
         self.h = C.c_void_p()
-        _check(lib().shp_server_start(arr, kinds, C.c_uint32(len(names)), C.c_uint32(height), C.c_char_p(host.encode()),
-                                      C.c_uint16(port), C.byref(self.h)))
+        opt = ServerOptions(struct_size=C.sizeof(ServerOptions), **options)
+        _check(lib().shp_server_start_ex(arr, kinds, C.c_uint32(len(flat)), C.c_uint32(height), C.c_char_p(host.encode()),
+                                         C.c_uint16(port), C.byref(opt), C.byref(self.h)))
         p = C.c_uint16()
         _check(lib().shp_server_port(self.h, C.byref(p)))
         self.port = p.value
@@ -735,6 +810,13 @@ class NativeServer:
         """(proofs answered, connections ended by an error, connections accepted)"""
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _check(lib().shp_server_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def timeouts(self):
+        """(requests that found every queue full for the spawn timeout, proofs abandoned at the run timeout, frames or
+        HTTP requests that stalled for the receive timeout)"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().shp_server_timeouts(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
     def close(self):

@@ -220,7 +220,7 @@ class PlanBuilder:
 
     # ---- derived quantities (halo2 ConstraintSystem::{degree, blinding_factors})
     def degree(self):
-        d = 3 if self.perm_cols else 1                  # permutation argument required degree
+        d = 3                 # halo2 v0.3.0 permutation::Argument::required_degree: 3 with or without equality columns
         for ins, tabs in self.lookups:
             di = max([1] + [e.degree for e in ins])
             dt = max([1] + [e.degree for e in tabs])

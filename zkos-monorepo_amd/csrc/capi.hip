@@ -105,7 +105,8 @@ static bool on_curve(const G1Affine& p) {
 
 using namespace shp;
 
-static void srs_finish(shp_srs* s) {
+// `share` (optional): an SRS over the same two bases whose MSM plans this one takes part in instead of building its own
+static void srs_finish(shp_srs* s, const shp_srs* share = nullptr) {
     {
         std::vector<uint8_t> m(4 + 3 * sizeof(G1Affine) + 256, 0);
         memcpy(m.data(), &s->k, 4);
@@ -116,6 +117,14 @@ static void srs_finish(shp_srs* s) {
             memcpy(m.data() + 4 + 3 * sizeof(G1Affine) + 128, s->s_g2, 128);
         }
         keccak256(m.data(), m.size(), s->fingerprint);
+    }
+    if (share) {
+        // same k, same points: the multiples tables (up to 228 GB at k = 13) exist once, whichever of the two is destroyed first
+        s->msm_gl = share->msm_gl;
+        s->msm_g = share->msm_g;
+        s->msm_gl->refs.fetch_add(1);
+        s->msm_g->refs.fetch_add(1);
+        return;
     }
     // the Lagrange basis first: it carries most of a proof's commitments and gets the larger share of the HBM
     msm_create_for_srs(s->ctx, s->d_gl, s->n, true, &s->msm_gl);
@@ -162,18 +171,30 @@ static void read_points(const uint8_t* p, size_t n, std::vector<G1Affine>& out) 
     }
 }
 
-// Proving lanes are HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (HIP's default is 4, and
-// hosts export that value explicitly) and the kernels of streams that share a queue run one after the other: 16 lanes
-// on 4 queues prove 1149 proofs/s, on 16 queues 1400.  A missing or smaller value is raised to 16 at load time, i.e.
-// before this library's first HIP call (SHP_KEEP_HW_QUEUES=1 leaves the environment alone); it has no effect if the
-// host process initialised HIP earlier.
+// Proving lanes are HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (HIP's default is 4) and the
+// kernels of streams that share a queue run one after the other: 16 lanes on 4 queues prove 1149 proofs/s, on 16 queues
+// 1400.  The setting is process-wide and belongs to the operator, so the library only fills in a default: when the
+// variable is UNSET at load time (before this library's first HIP call) it becomes 16.  An exported value is never
+// overwritten -- a smaller one earns one line on stderr (SHP_KEEP_HW_QUEUES=1 silences it) -- unless the operator asks
+// for it: SHP_HW_QUEUES=N in the environment makes the library set GPU_MAX_HW_QUEUES=N.  None of this has an effect if
+// the host process initialised HIP earlier.
 namespace {
 struct HwQueueDefault {
     HwQueueDefault() {
-        const char* keep = getenv("SHP_KEEP_HW_QUEUES");
-        if (keep && atoi(keep) == 1) return;
+        if (const char* want = getenv("SHP_HW_QUEUES")) {
+            const int n = atoi(want);
+            if (n >= 1 && n <= 32) setenv("GPU_MAX_HW_QUEUES", want, 1);
+            return;
+        }
         const char* cur = getenv("GPU_MAX_HW_QUEUES");
-        if (!cur || atoi(cur) < 16) setenv("GPU_MAX_HW_QUEUES", "16", 1);
+        if (!cur || !*cur) {
+            setenv("GPU_MAX_HW_QUEUES", "16", 1);
+            return;
+        }
+        const char* keep = getenv("SHP_KEEP_HW_QUEUES");
+        if (atoi(cur) < 16 && !(keep && atoi(keep) == 1))
+            fprintf(stderr, "[shielder_hip] GPU_MAX_HW_QUEUES=%s: proving lanes beyond that many share hardware queues and run one after "
+                            "the other; SHP_HW_QUEUES=16..22 raises it for this process, SHP_KEEP_HW_QUEUES=1 silences this line\n", cur);
     }
 } g_hw_queue_default;
 }  // namespace
@@ -227,6 +248,7 @@ int32_t shp_ctx_create(int32_t device, shp_ctx** out) {
 int32_t shp_ctx_destroy(shp_ctx* ctx) {
     return guarded([&] {
         if (!ctx) return;
+        (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
         for (int d = 0; d < 2; d++)
             if (ctx->ntt_small[d]) (void)hipFree(ctx->ntt_small[d]);
@@ -277,6 +299,7 @@ int32_t shp_ctx_stream(shp_ctx* ctx, void** stream_out) {
 int32_t shp_malloc(shp_ctx* ctx, size_t bytes, void** d_out) {
     return guarded([&] {
         SHP_REQUIRE(ctx && d_out, SHP_ERR_INVALID_ARG, "malloc: null argument");
+        SHP_HIP(hipSetDevice(ctx->device));
         SHP_HIP(hipMalloc(d_out, bytes ? bytes : 1));
     });
 }
@@ -289,6 +312,7 @@ int32_t shp_free(shp_ctx* ctx, void* d_ptr) {
 int32_t shp_upload(shp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
     return guarded([&] {
         SHP_REQUIRE(ctx && d_dst && h_src, SHP_ERR_INVALID_ARG, "upload: null argument");
+        SHP_HIP(hipSetDevice(ctx->device));
         SHP_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
         SHP_HIP(hipStreamSynchronize(ctx->stream));
     });
@@ -296,6 +320,7 @@ int32_t shp_upload(shp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
 int32_t shp_download(shp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
     return guarded([&] {
         SHP_REQUIRE(ctx && h_dst && d_src, SHP_ERR_INVALID_ARG, "download: null argument");
+        SHP_HIP(hipSetDevice(ctx->device));
         SHP_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         SHP_HIP(hipStreamSynchronize(ctx->stream));
     });
@@ -390,6 +415,7 @@ int32_t shp_encode_calldata(const uint8_t* proof, size_t proof_len, const uint8_
 int32_t shp_ntt_fr(shp_ctx* ctx, void* d_data, uint32_t log_n, uint32_t batch, int32_t inverse, void* stream) {
     return guarded([&] {
         SHP_REQUIRE(ctx && d_data, SHP_ERR_INVALID_ARG, "ntt: null argument");
+        SHP_HIP(hipSetDevice(ctx->device));
         NttOpts o;
         o.inverse = inverse != 0;
         ntt_launch(ctx, (const Fr*)d_data, (Fr*)d_data, log_n, batch, o, ctx->pick(stream));
@@ -402,6 +428,7 @@ int32_t shp_coeff_to_extended(shp_ctx* ctx, const void* d_in, void* d_out, uint3
         SHP_REQUIRE(ctx && d_in && d_out, SHP_ERR_INVALID_ARG, "coeff_to_extended: null argument");
         SHP_REQUIRE(ext_k >= k, SHP_ERR_INVALID_ARG, "coeff_to_extended: ext_k < k");
         SHP_REQUIRE(d_in != d_out, SHP_ERR_INVALID_ARG, "coeff_to_extended: must be out of place");
+        SHP_HIP(hipSetDevice(ctx->device));
         NttOpts o;
         o.in_len = 1u << k;
         o.in_stride = (size_t)1 << k;
@@ -413,6 +440,7 @@ int32_t shp_coeff_to_extended(shp_ctx* ctx, const void* d_in, void* d_out, uint3
 int32_t shp_extended_to_coeff(shp_ctx* ctx, void* d_data, uint32_t ext_k, uint32_t batch, void* stream) {
     return guarded([&] {
         SHP_REQUIRE(ctx && d_data, SHP_ERR_INVALID_ARG, "extended_to_coeff: null argument");
+        SHP_HIP(hipSetDevice(ctx->device));
         NttOpts o;
         o.inverse = true;
         o.post_pattern = 1;
@@ -426,6 +454,7 @@ int32_t shp_srs_from_parts(shp_ctx* ctx, uint32_t k, const void* h_g, const void
     return guarded([&] {
         SHP_REQUIRE(ctx && h_g && out, SHP_ERR_INVALID_ARG, "srs_from_parts: null argument");
         SHP_REQUIRE(k >= 1 && k <= 24, SHP_ERR_INVALID_ARG, "srs_from_parts: k out of range");
+        SHP_HIP(hipSetDevice(ctx->device));
         shp_srs* s = new shp_srs;
         try {
             s->ctx = ctx;
@@ -456,6 +485,7 @@ int32_t shp_srs_downsize(const shp_srs* srs, uint32_t k, shp_srs** out) {
     return guarded([&] {
         SHP_REQUIRE(srs && out, SHP_ERR_INVALID_ARG, "srs_downsize: null argument");
         SHP_REQUIRE(k >= 1 && k <= srs->k, SHP_ERR_INVALID_ARG, "srs_downsize: k must not exceed the SRS's k");
+        SHP_HIP(hipSetDevice(srs->ctx->device));
         shp_srs* s = new shp_srs;
         try {
             s->ctx = srs->ctx;
@@ -469,7 +499,7 @@ int32_t shp_srs_downsize(const shp_srs* srs, uint32_t k, shp_srs** out) {
             memcpy(s->g2, srs->g2, 128);
             memcpy(s->s_g2, srs->s_g2, 128);
             s->has_g2 = srs->has_g2;
-            srs_finish(s);
+            srs_finish(s, k == srs->k ? srs : nullptr);
         } catch (...) {
             srs_release(s);
             throw;
@@ -482,6 +512,7 @@ int32_t shp_srs_synthetic(shp_ctx* ctx, uint32_t k, const uint8_t tau_le32[32], 
     return guarded([&] {
         SHP_REQUIRE(ctx && tau_le32 && out, SHP_ERR_INVALID_ARG, "srs_synthetic: null argument");
         SHP_REQUIRE(k >= 1 && k <= 20, SHP_ERR_INVALID_ARG, "srs_synthetic: k out of range");
+        SHP_HIP(hipSetDevice(ctx->device));
         Fr raw;
         memcpy(raw.l, tau_le32, 32);
         SHP_REQUIRE(!raw.geq_p(), SHP_ERR_FORMAT, "srs_synthetic: tau is not a canonical field element");
@@ -609,6 +640,7 @@ int32_t shp_srs_commit(shp_srs* srs, int32_t basis, const void* d_polys, uint32_
                        void* stream) {
     return guarded([&] {
         SHP_REQUIRE(srs && d_polys && h_out_affine, SHP_ERR_INVALID_ARG, "srs_commit: null argument");
+        SHP_HIP(hipSetDevice(srs->ctx->device));
         shp_msm* m = basis == SHP_BASIS_LAGRANGE ? srs->msm_gl : srs->msm_g;
         msm_run(m, (const Fr*)d_polys, srs->n, srs->n, batch, (G1Affine*)h_out_affine, srs->ctx->pick(stream));
     });

@@ -19,6 +19,7 @@ using namespace shp;
 extern "C" int32_t shp_diag_fr_mul_rate(shp_ctx* ctx, uint32_t iters, double* muls_per_sec) {
     return guarded([&] {
         SHP_REQUIRE(ctx && muls_per_sec, SHP_ERR_INVALID_ARG, "diag: null argument");
+        SHP_HIP(hipSetDevice(ctx->device));
         const uint32_t blocks = (uint32_t)ctx->num_cus * 8, threads = 256;
         Fr* d = nullptr;
         SHP_HIP(hipMalloc(&d, (size_t)blocks * threads * sizeof(Fr)));

@@ -96,6 +96,7 @@ struct shp_msm {
     shp::Fr bias;                         // signed-digit bias of the direct mode
     shp::MsmWorkspace ws;
     std::mutex mu;
+    std::atomic<int> refs{1};             // an SRS downsized to its own k shares its parent's plans (shp_msm_destroy drops one)
     ~shp_msm() {                          // also runs when plan construction throws half way
         if (d_table) (void)hipFree(d_table);
         if (d_mult) (void)hipFree(d_mult);

@@ -1071,6 +1071,7 @@ static void msm_build_direct(shp_ctx* ctx, shp_msm* m, const G1Affine* d_bases) 
 static void msm_build(shp_ctx* ctx, const G1Affine* d_bases, size_t n, uint32_t window_bits, shp_msm** out,
                       TableRole role = TableRole::Single) {
     SHP_REQUIRE(ctx && out && n > 0, SHP_ERR_INVALID_ARG, "msm_create: bad arguments");
+    SHP_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<shp_msm> m(new shp_msm);
     m->ctx = ctx;
     m->n = n;
@@ -1467,6 +1468,7 @@ int32_t shp_msm_create_dev(shp_ctx* ctx, const void* d_bases, size_t n, uint32_t
 int32_t shp_msm_create(shp_ctx* ctx, const void* h_bases, size_t n, uint32_t window_bits, shp_msm** out) {
     return guarded([&] {
         SHP_REQUIRE(ctx && h_bases && n > 0, SHP_ERR_INVALID_ARG, "msm_create: bad arguments");
+        SHP_HIP(hipSetDevice(ctx->device));
         G1Affine* d = nullptr;
         SHP_HIP(hipMalloc(&d, n * sizeof(G1Affine)));
         hipError_t e = hipMemcpy(d, h_bases, n * sizeof(G1Affine), hipMemcpyHostToDevice);
@@ -1483,7 +1485,7 @@ int32_t shp_msm_create(shp_ctx* ctx, const void* h_bases, size_t n, uint32_t win
 
 int32_t shp_msm_destroy(shp_msm* m) {
     return guarded([&] {
-        delete m;                         // ~shp_msm frees the tables and the workspace
+        if (m && m->refs.fetch_sub(1) == 1) delete m;      // ~shp_msm frees the tables and the workspace
     });
 }
 
@@ -1491,6 +1493,7 @@ int32_t shp_msm_g1(shp_msm* m, const void* d_scalars, size_t n_scalars, size_t s
                    void* h_out_affine, void* stream) {
     return guarded([&] {
         SHP_REQUIRE(m, SHP_ERR_INVALID_ARG, "msm: null plan");
+        SHP_HIP(hipSetDevice(m->ctx->device));
         msm_run(m, (const Fr*)d_scalars, n_scalars, stride_elems ? stride_elems : n_scalars, batch,
                 (G1Affine*)h_out_affine, m->ctx->pick(stream));
     });
@@ -1501,6 +1504,32 @@ int32_t shp_msm_last_stats(shp_msm* m, uint64_t* point_adds, uint64_t* bytes) {
         SHP_REQUIRE(m, SHP_ERR_INVALID_ARG, "msm: null plan");
         if (point_adds) *point_adds = m->ws.last_adds;
         if (bytes) *bytes = m->ws.last_bytes;
+    });
+}
+
+int32_t shp_diag_multiples(shp_ctx* ctx, const void* d_bases, size_t n_rows, uint32_t multiples, void* d_out) {
+    return guarded([&] {
+        SHP_REQUIRE(ctx && d_bases && d_out && n_rows >= 1, SHP_ERR_INVALID_ARG, "diag_multiples: null argument");
+        SHP_REQUIRE(multiples >= 64 && multiples <= (1u << 16) && (multiples & (multiples - 1)) == 0, SHP_ERR_INVALID_ARG,
+                    "diag_multiples: multiples must be a power of two in [64, 65536]");
+        SHP_REQUIRE((uint64_t)n_rows * multiples <= (1ull << 26), SHP_ERR_INVALID_ARG, "diag_multiples: more than 2^26 points");
+        SHP_HIP(hipSetDevice(ctx->device));
+        size_t batch_rows = std::max<size_t>(1, ((size_t)1 << 23) / multiples);
+        if (batch_rows > n_rows) batch_rows = n_rows;
+        DevBuf xyzz, pre;
+        xyzz.reserve(batch_rows * multiples * sizeof(G1X));
+        pre.reserve(batch_rows * multiples * sizeof(Fq));
+        for (size_t r0 = 0; r0 < n_rows; r0 += batch_rows) {
+            const uint32_t nr = (uint32_t)std::min(batch_rows, n_rows - r0);
+            hipLaunchKernelGGL(msm_multiples_kernel, dim3(nr), dim3(64), 0, ctx->stream, (const G1Affine*)d_bases, r0, nr, multiples,
+                               xyzz.as<G1X>(), pre.as<Fq>(), (G1Affine*)d_out);
+        }
+        hipError_t e = hipGetLastError();
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        xyzz.release();
+        pre.release();
+        SHP_HIP(e);
+        SHP_HIP(e2);
     });
 }
 

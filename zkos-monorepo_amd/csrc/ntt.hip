@@ -426,6 +426,7 @@ extern "C" int32_t shp_ntt_fr_noalloc(shp_ctx* ctx, void* d_data, uint32_t log_n
         SHP_REQUIRE(((uint64_t)batch << log_n) <= (1ull << NTT_STATIC_LOG), SHP_ERR_INVALID_ARG,
                     "ntt_noalloc: batch * 2^log_n exceeds the 2^20 elements of the static ping-pong array");
         SHP_REQUIRE(ctx->ntt_static_tmp && ctx->ntt_master_lo[0], SHP_ERR_INTERNAL, "ntt_noalloc: context not set up");
+        SHP_HIP(hipSetDevice(ctx->device));
         if (batch == 0) return;
         NttTables T;
         T.log_n = log_n;

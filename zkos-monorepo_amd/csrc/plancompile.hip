@@ -183,6 +183,12 @@ void compile_description(const uint8_t* d, size_t len, std::vector<uint8_t>& out
     SHP_REQUIRE(P.k >= 4 && P.k <= 20 && P.num_advice >= 1 && P.num_advice <= 1024 && P.num_fixed <= 1024 && P.num_instance <= 1024 &&
                     npc <= 1024 && nlk <= 64 && nn <= (1u << 24) && ng <= (1u << 20) && ncst <= (1u << 20) && has_map <= 1,
                 SHP_ERR_FORMAT, "circuit description: implausible header");
+    // every count is followed by at least that many fixed-size records: one that the remaining bytes cannot hold is
+    // refused before anything is sized by it (queries 8 B, permutation columns 8 B, constants 32 B, nodes 12 B, roots 4 B,
+    // copy constraints 24 B, witness operations 32 B, instance cells 8 B)
+    SHP_REQUIRE((uint64_t)naq * 8 + (uint64_t)nfq * 8 + (uint64_t)niq * 8 + (uint64_t)npc * 8 + (uint64_t)ncst * 32 + (uint64_t)nn * 12 +
+                        (uint64_t)ng * 4 + (has_map ? 0 : (uint64_t)ncp * 24) + (uint64_t)nwo * 32 + (uint64_t)nim * 8 <= len,
+                SHP_ERR_FORMAT, "circuit description: header counts exceed the description's length");
     P.n = 1u << P.k;
     const uint32_t n = P.n;
     auto queries = [&](std::vector<Query>& v, uint32_t cnt, uint32_t ncols) {
@@ -230,8 +236,10 @@ void compile_description(const uint8_t* d, size_t len, std::vector<uint8_t>& out
     std::vector<uint32_t> gates(ng);
     for (auto& g : gates) g = root();
     P.num_gates = ng;
-    // halo2 ConstraintSystem::degree: permutation argument 3, each lookup max(4, 2 + deg(input) + deg(table)), gates
-    uint32_t degree = npc ? 3 : 1;
+    // halo2 ConstraintSystem::degree: the permutation argument's required degree is 3 whether or not any column is
+    // equality-enabled (halo2 v0.3.0 permutation::Argument::required_degree), each lookup max(4, 2 + deg(input) +
+    // deg(table)), then the gates
+    uint32_t degree = 3;
     for (uint32_t g : gates) degree = std::max(degree, C.degree[g]);
     C.compile(gates, P.gate_prog, P.gate_slots);
     P.lookups.resize(nlk);

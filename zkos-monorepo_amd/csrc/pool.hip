@@ -8,6 +8,7 @@
 // lane = one HIP stream + workspace, and shp_prove_batch is the batch entry point:
 // `count` independent proofs sharded over the lanes of this GPU.  No CPU fallback anywhere.
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -26,6 +27,7 @@ struct Job {
     size_t n_inputs = 0;
     // result
     bool done = false;
+    bool abandoned = false;      // its waiter gave up (shp_pool_wait_for timed out): a lane that has not started it skips it
     int32_t status = SHP_OK;
     std::string error;
     std::vector<uint8_t> proof, instances;
@@ -47,6 +49,7 @@ struct shp_pool {
     uint64_t next_ticket = 1;
     bool stopping = false;
     std::atomic<uint64_t> proofs_done{0};
+    std::atomic<uint64_t> outstanding{0};                // jobs accepted and not finished: queued or on a lane
     shp::MsmCombiner* comb = nullptr;      // SHP_POOL_COMBINE=1: one MSM launch serves every lane waiting at a commitment
 
     void worker(shp_prover* lane) {
@@ -59,6 +62,11 @@ struct shp_pool {
                 if (queue.empty()) return;               // stopping and drained
                 j = queue.front();
                 queue.pop_front();
+                if (j->abandoned) {                      // nobody will collect it: the lane goes to the next job
+                    j->done = true;
+                    outstanding--;
+                    continue;
+                }
             }
             j->proof.resize(proof_len);
             j->instances.resize((size_t)n_instances * 32);
@@ -74,6 +82,7 @@ struct shp_pool {
                 j->done = true;
             }
             proofs_done++;
+            outstanding--;
             cv_done.notify_all();
         }
     }
@@ -171,33 +180,59 @@ int32_t shp_pool_submit(shp_pool* p, const uint8_t* witness_le32, size_t n_input
             j->ticket = p->next_ticket++;
             p->queue.push_back(j);
             p->jobs[j->ticket] = j;
+            p->outstanding++;
             *ticket = j->ticket;
         }
         p->cv_work.notify_one();
     });
 }
 
+static void pool_wait_impl(shp_pool* p, uint64_t ticket, int64_t timeout_ms, uint8_t* proof_out, size_t proof_cap,
+                           size_t* proof_len, uint8_t* instances_le32, size_t instances_cap) {
+    SHP_REQUIRE(p && proof_out && proof_len, SHP_ERR_INVALID_ARG, "pool_wait: null argument");
+    std::shared_ptr<Job> j;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        auto it = p->jobs.find(ticket);
+        SHP_REQUIRE(it != p->jobs.end(), SHP_ERR_INVALID_ARG, "pool_wait: unknown ticket");
+        j = it->second;
+        if (timeout_ms < 0) {
+            p->cv_done.wait(lk, [&] { return j->done; });
+        } else if (!p->cv_done.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return j->done; })) {
+            // the reference's run timeout drops the task's future (tokio_task_pool with_run_timeout,
+            // /root/reference/tee/crates/shielder-prover-server/src/main.rs:42-45): the ticket is gone, a proof that
+            // is already on a lane still finishes there and is discarded
+            j->abandoned = true;
+            p->jobs.erase(it);
+            throw shp::Error(SHP_ERR_TIMEOUT, "pool_wait_for: the proof did not finish in time; the ticket is abandoned");
+        }
+        p->jobs.erase(it);
+    }
+    if (j->status != SHP_OK) throw shp::Error(j->status, j->error);
+    SHP_REQUIRE(j->proof.size() <= proof_cap, SHP_ERR_INVALID_ARG, "pool_wait: proof buffer too small");
+    memcpy(proof_out, j->proof.data(), j->proof.size());
+    *proof_len = j->proof.size();
+    if (instances_le32) {
+        SHP_REQUIRE(j->instances.size() <= instances_cap, SHP_ERR_INVALID_ARG, "pool_wait: instance buffer too small");
+        memcpy(instances_le32, j->instances.data(), j->instances.size());
+    }
+}
+
 int32_t shp_pool_wait(shp_pool* p, uint64_t ticket, uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
                       uint8_t* instances_le32, size_t instances_cap) {
+    return shp::guarded([&] { pool_wait_impl(p, ticket, -1, proof_out, proof_cap, proof_len, instances_le32, instances_cap); });
+}
+
+int32_t shp_pool_wait_for(shp_pool* p, uint64_t ticket, uint32_t timeout_ms, uint8_t* proof_out, size_t proof_cap,
+                          size_t* proof_len, uint8_t* instances_le32, size_t instances_cap) {
+    return shp::guarded(
+        [&] { pool_wait_impl(p, ticket, (int64_t)timeout_ms, proof_out, proof_cap, proof_len, instances_le32, instances_cap); });
+}
+
+int32_t shp_pool_outstanding(const shp_pool* p, uint64_t* jobs) {
     return shp::guarded([&] {
-        SHP_REQUIRE(p && proof_out && proof_len, SHP_ERR_INVALID_ARG, "pool_wait: null argument");
-        std::shared_ptr<Job> j;
-        {
-            std::unique_lock<std::mutex> lk(p->mu);
-            auto it = p->jobs.find(ticket);
-            SHP_REQUIRE(it != p->jobs.end(), SHP_ERR_INVALID_ARG, "pool_wait: unknown ticket");
-            j = it->second;
-            p->cv_done.wait(lk, [&] { return j->done; });
-            p->jobs.erase(it);
-        }
-        if (j->status != SHP_OK) throw shp::Error(j->status, j->error);
-        SHP_REQUIRE(j->proof.size() <= proof_cap, SHP_ERR_INVALID_ARG, "pool_wait: proof buffer too small");
-        memcpy(proof_out, j->proof.data(), j->proof.size());
-        *proof_len = j->proof.size();
-        if (instances_le32) {
-            SHP_REQUIRE(j->instances.size() <= instances_cap, SHP_ERR_INVALID_ARG, "pool_wait: instance buffer too small");
-            memcpy(instances_le32, j->instances.data(), j->instances.size());
-        }
+        SHP_REQUIRE(p && jobs, SHP_ERR_INVALID_ARG, "pool_outstanding: null argument");
+        *jobs = p->outstanding.load();
     });
 }
 
@@ -221,6 +256,7 @@ int32_t shp_prove_batch(shp_pool* p, const uint8_t* witnesses_le32, size_t n_inp
                 j->n_inputs = n_inputs;
                 j->ticket = p->next_ticket++;
                 p->queue.push_back(j);
+                p->outstanding++;
                 js[i] = j;
             }
         }

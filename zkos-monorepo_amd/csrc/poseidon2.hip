@@ -223,6 +223,7 @@ int32_t shp_poseidon2_t8(shp_ctx* ctx, const void* d_in, size_t n_hashes, uint32
         SHP_REQUIRE(ctx && d_in && d_out, SHP_ERR_INVALID_ARG, "poseidon2: null argument");
         SHP_REQUIRE(arity >= 1 && arity <= 7, SHP_ERR_INVALID_ARG, "poseidon2: arity must be in 1..7");
         if (!n_hashes) return;
+        SHP_HIP(hipSetDevice(ctx->device));
         hipLaunchKernelGGL(poseidon2_hash_kernel, dim3(ceil_div(n_hashes, 128)), dim3(128), 0, ctx->pick(stream),
                            (const Fr*)d_in, n_hashes, arity, (Fr*)d_out);
         SHP_HIP(hipGetLastError());
@@ -233,6 +234,7 @@ int32_t shp_poseidon2_t8_permute(shp_ctx* ctx, void* d_states, size_t n_states, 
     return guarded([&] {
         SHP_REQUIRE(ctx && d_states, SHP_ERR_INVALID_ARG, "poseidon2: null argument");
         if (!n_states) return;
+        SHP_HIP(hipSetDevice(ctx->device));
         hipLaunchKernelGGL(poseidon2_permute_kernel, dim3(ceil_div(n_states, 128)), dim3(128), 0, ctx->pick(stream),
                            (Fr*)d_states, n_states);
         SHP_HIP(hipGetLastError());

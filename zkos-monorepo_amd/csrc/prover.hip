@@ -103,6 +103,7 @@ struct shp_pk {
     // host copies
     std::vector<G1Affine> fixed_comm, sigma_comm;
     uint8_t vk_digest[32];
+    uint8_t own_digest[32];                        // the library's Keccak digest over plan and commitments, whatever vk_digest is
     bool digest_injected = false;                  // vk_digest = the caller's transcript_repr, not the library's own
     std::vector<uint8_t> plan_bytes;               // the circuit plan the key was generated from (shp_pk_save)
     Fr omega, omega_inv, delta, zeta;
@@ -425,6 +426,7 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
         raw.l[i] = ((uint32_t)h[31 - 4 * i]) | ((uint32_t)h[30 - 4 * i] << 8) | ((uint32_t)h[29 - 4 * i] << 16) |
                    ((uint32_t)h[28 - 4 * i] << 24);
     to_be32(Fr::from_raw(raw), pk->vk_digest);
+    memcpy(pk->own_digest, pk->vk_digest, 32);
     if (transcript_repr_le32) {
         Fr t;
         memcpy(t.l, transcript_repr_le32, 32);
@@ -769,6 +771,7 @@ static void set_witness_threads(shp_prover* pr, uint32_t threads) {
 
 static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     SHP_REQUIRE(pk && out, SHP_ERR_INVALID_ARG, "prover_create: null argument");
+    SHP_HIP(hipSetDevice(pk->ctx->device));          // contexts of several GPUs may live in one process
     std::unique_ptr<shp_prover> pr(new shp_prover);
     pr->pk = pk;
     SHP_HIP(hipStreamCreateWithFlags(&pr->st, hipStreamNonBlocking));
@@ -1585,13 +1588,13 @@ int32_t shp_blinding_stream(const uint8_t seed[32], uint64_t first, size_t count
 // flags bit 0: the digest is a caller-supplied transcript_repr (shp_keygen_with_transcript_repr), not the library's own.
 // The SRS fingerprint (Keccak over k, g[0], g[1], g_lagrange[0], g2, s_g2) binds the key to the SRS its commitments were
 // computed over: loading it against another SRS of the same k fails instead of yielding proofs that never verify.
-static const char PK_MAGIC[8] = {'S', 'H', 'P', 'K', '0', '0', '0', '2'};
+static const char PK_MAGIC[8] = {'S', 'H', 'P', 'K', '0', '0', '0', '3'};
 
 int32_t shp_pk_save(const shp_pk* pk, uint8_t* out, size_t out_cap, size_t* out_len) {
     return guarded([&] {
         SHP_REQUIRE(pk && out_len, SHP_ERR_INVALID_ARG, "pk_save: null argument");
         const uint32_t F = (uint32_t)pk->fixed_comm.size(), PC = (uint32_t)pk->sigma_comm.size();
-        const size_t total = 8 + 4 + 4 + 32 + 4 + pk->plan_bytes.size() + 4 + 4 + (size_t)(F + PC) * sizeof(G1Affine) + 32;
+        const size_t total = 8 + 4 + 4 + 32 + 4 + pk->plan_bytes.size() + 4 + 4 + (size_t)(F + PC) * sizeof(G1Affine) + 64;
         *out_len = total;
         if (!out) return;
         SHP_REQUIRE(out_cap >= total, SHP_ERR_INVALID_ARG, "pk_save: buffer too small");
@@ -1603,6 +1606,7 @@ int32_t shp_pk_save(const shp_pk* pk, uint8_t* out, size_t out_cap, size_t* out_
         put(pk->fixed_comm.data(), (size_t)F * sizeof(G1Affine));
         put(pk->sigma_comm.data(), (size_t)PC * sizeof(G1Affine));
         put(pk->vk_digest, 32);
+        put(pk->own_digest, 32);        // the integrity check of a key whose vk_digest is the caller's transcript_repr
     });
 }
 
@@ -1628,11 +1632,11 @@ int32_t shp_pk_load(shp_ctx* ctx, shp_srs* srs, const uint8_t* bytes, size_t len
         memcpy(&F, p, 4); memcpy(&PC, p + 4, 4);
         p += 8;
         SHP_REQUIRE(F <= 4096 && PC <= MAX_PERM_COLS, SHP_ERR_FORMAT, "pk_load: implausible column counts");
-        need((size_t)(F + PC) * sizeof(G1Affine) + 32);
+        need((size_t)(F + PC) * sizeof(G1Affine) + 64);
         std::vector<G1Affine> comm(F + PC);
         memcpy(comm.data(), p, comm.size() * sizeof(G1Affine));
         p += comm.size() * sizeof(G1Affine);
-        SHP_REQUIRE(p + 32 == end, SHP_ERR_FORMAT, "pk_load: trailing bytes");
+        SHP_REQUIRE(p + 64 == end, SHP_ERR_FORMAT, "pk_load: trailing bytes");
         uint8_t repr_le[32];
         for (int i = 0; i < 32; i++) repr_le[i] = p[31 - i];       // the digest is stored big-endian, as absorbed
         shp_pk* pk = nullptr;
@@ -1642,7 +1646,10 @@ int32_t shp_pk_load(shp_ctx* ctx, shp_srs* srs, const uint8_t* bytes, size_t len
         // The library's own digest is recomputed from the stored plan and commitments: accidental corruption of either
         // does not load.  (It does not prove that the commitments ARE the plan's: that would take the MSMs the saved
         // form exists to avoid; a key file is trusted input, like the reference's pk.bin.)
-        SHP_REQUIRE(memcmp(pk->vk_digest, p, 32) == 0, SHP_ERR_FORMAT, "pk_load: verifying-key digest mismatch");
+        // A key made with a caller-supplied transcript_repr takes its vk_digest from the file, so that comparison proves
+        // nothing for it: the library's own digest is stored beside it and checked for every key.
+        SHP_REQUIRE(memcmp(pk->vk_digest, p, 32) == 0 && memcmp(pk->own_digest, p + 32, 32) == 0, SHP_ERR_FORMAT,
+                    "pk_load: verifying-key digest mismatch");
         *out = guard.release();
     });
 }

@@ -206,6 +206,87 @@ void b64(const uint8_t* d, size_t n, std::string& out) {
     }
 }
 
+
+// standard base64 with padding, as the reference's base64_serialization writes it (general_purpose::STANDARD)
+void b64_decode(const std::string& in, std::vector<uint8_t>& out) {
+    auto val = [](char ch) -> int {
+        if (ch >= 'A' && ch <= 'Z') return ch - 'A';
+        if (ch >= 'a' && ch <= 'z') return ch - 'a' + 26;
+        if (ch >= '0' && ch <= '9') return ch - '0' + 52;
+        if (ch == '+') return 62;
+        if (ch == '/') return 63;
+        return -1;
+    };
+    out.clear();
+    if (in.size() % 4) bad("base64: length is not a multiple of four");
+    out.reserve(in.size() / 4 * 3);
+    for (size_t i = 0; i < in.size(); i += 4) {
+        const bool last = i + 4 == in.size();
+        const int pad = last ? (in[i + 3] == '=' ? (in[i + 2] == '=' ? 2 : 1) : 0) : 0;
+        int v[4] = {val(in[i]), val(in[i + 1]), pad >= 2 ? 0 : val(in[i + 2]), pad >= 1 ? 0 : val(in[i + 3])};
+        if (v[0] < 0 || v[1] < 0 || v[2] < 0 || v[3] < 0) bad("base64: invalid character");
+        const uint32_t w = (uint32_t)v[0] << 18 | (uint32_t)v[1] << 12 | (uint32_t)v[2] << 6 | (uint32_t)v[3];
+        if ((pad == 2 && (w & 0xFFFF)) || (pad == 1 && (w & 0xFF))) bad("base64: non-zero trailing bits");
+        out.push_back((uint8_t)(w >> 16));
+        if (pad < 2) out.push_back((uint8_t)(w >> 8));
+        if (pad < 1) out.push_back((uint8_t)w);
+    }
+}
+
+// Payload { circuit_type, user_public_key, circuit_inputs } (protocol.rs:14-20) -> the circuit's prove() arguments
+void decode_payload(const std::vector<uint8_t>& payload, uint32_t height, int32_t* circuit, uint8_t* witness_le32,
+                    size_t witness_cap, size_t* n_inputs) {
+    std::vector<uint8_t> inner, field;
+    auto once = [](bool& flag) {
+        if (flag) bad("duplicate field");
+        flag = true;
+    };
+    std::string ctype;
+    bool have_inputs = false, have_key = false, have_type = false;
+    Cur pc{payload.data(), payload.data() + payload.size()};
+    object(pc, [&](const std::string& k, Cur& cc) {
+        if (k == "circuit_type") { once(have_type); ctype = str(cc); }
+        else if (k == "user_public_key") { once(have_key); bytes_array(cc, field); }
+        else if (k == "circuit_inputs") { once(have_inputs); bytes_array(cc, inner); }
+        else skip(cc);
+    });
+    end_of_input(pc);
+    if (!have_inputs || !have_key) bad("payload: missing fields");
+    if (ctype == "Withdraw") *circuit = SHP_TEE_WITHDRAW;
+    else if (ctype == "Deposit") *circuit = SHP_TEE_DEPOSIT;
+    else if (ctype == "NewAccount") *circuit = SHP_TEE_NEW_ACCOUNT;
+    else bad("payload: bad circuit_type");
+    const CircuitShape& sh = shape_of(*circuit);
+    // witness layout: the circuit's prove() arguments in order, 32 bytes each, the path height x 7 x 32
+    const size_t path_bytes = (size_t)32 * 7 * height;
+    size_t offset[16], total = 0;
+    for (int f = 0; f < sh.n_fields; f++) { offset[f] = total; total += f == sh.path_index ? path_bytes : 32; }
+    SHP_REQUIRE(witness_le32 && witness_cap >= total, SHP_ERR_INVALID_ARG, "tee_decode_request: witness buffer too small");
+    bool seen[16] = {false};
+    Cur ic{inner.data(), inner.data() + inner.size()};
+    object(ic, [&](const std::string& k, Cur& cc) {
+        int f = -1;
+        for (int i = 0; i < sh.n_fields; i++)
+            if (k == sh.fields[i]) f = i;
+        if (f < 0) { skip(cc); return; }
+        if (seen[f]) bad("duplicate field");
+        bytes_array(cc, field);
+        const size_t want = f == sh.path_index ? path_bytes : 32;
+        if (field.size() != want) bad("circuit_inputs: field of the wrong length");
+        for (size_t o = 0; o < want; o += 32) {          // vec_to_f panics on a non-canonical element (utils.rs:33)
+            shp::Fr raw;
+            memcpy(raw.l, field.data() + o, 32);
+            if (raw.geq_p()) bad("circuit_inputs: not a canonical field element");
+        }
+        memcpy(witness_le32 + offset[f], field.data(), want);
+        seen[f] = true;
+    });
+    end_of_input(ic);
+    for (int f = 0; f < sh.n_fields; f++)
+        if (!seen[f]) bad("circuit_inputs: missing field");
+    *n_inputs = total / 32;
+}
+
 }  // namespace
 
 extern "C" {
@@ -227,7 +308,7 @@ int32_t shp_tee_decode_request(const uint8_t* json, size_t len, uint32_t height,
         }
         // serde rejects a field that appears twice ("duplicate field") and an externally tagged enum with more
         // than one key; ignored (unknown) fields may repeat
-        std::vector<uint8_t> payload, inner, field;
+        std::vector<uint8_t> payload;
         bool have_payload = false, have_variant = false;
         auto once = [](bool& flag) {
             if (flag) bad("duplicate field");
@@ -244,51 +325,7 @@ int32_t shp_tee_decode_request(const uint8_t* json, size_t len, uint32_t height,
         end_of_input(c);
         if (!have_payload) bad("GenerateProof without payload");
         *kind = SHP_TEE_GENERATE_PROOF;
-        // Payload { circuit_type, user_public_key, circuit_inputs }
-        std::string ctype;
-        bool have_inputs = false, have_key = false, have_type = false;
-        Cur pc{payload.data(), payload.data() + payload.size()};
-        object(pc, [&](const std::string& k, Cur& cc) {
-            if (k == "circuit_type") { once(have_type); ctype = str(cc); }
-            else if (k == "user_public_key") { once(have_key); bytes_array(cc, field); }
-            else if (k == "circuit_inputs") { once(have_inputs); bytes_array(cc, inner); }
-            else skip(cc);
-        });
-        end_of_input(pc);
-        if (!have_inputs || !have_key) bad("payload: missing fields");
-        if (ctype == "Withdraw") *circuit = SHP_TEE_WITHDRAW;
-        else if (ctype == "Deposit") *circuit = SHP_TEE_DEPOSIT;
-        else if (ctype == "NewAccount") *circuit = SHP_TEE_NEW_ACCOUNT;
-        else bad("payload: bad circuit_type");
-        const CircuitShape& sh = shape_of(*circuit);
-        // witness layout: the circuit's prove() arguments in order, 32 bytes each, the path height x 7 x 32
-        const size_t path_bytes = (size_t)32 * 7 * height;
-        size_t offset[16], total = 0;
-        for (int f = 0; f < sh.n_fields; f++) { offset[f] = total; total += f == sh.path_index ? path_bytes : 32; }
-        SHP_REQUIRE(witness_le32 && witness_cap >= total, SHP_ERR_INVALID_ARG, "tee_decode_request: witness buffer too small");
-        bool seen[16] = {false};
-        Cur ic{inner.data(), inner.data() + inner.size()};
-        object(ic, [&](const std::string& k, Cur& cc) {
-            int f = -1;
-            for (int i = 0; i < sh.n_fields; i++)
-                if (k == sh.fields[i]) f = i;
-            if (f < 0) { skip(cc); return; }
-            if (seen[f]) bad("duplicate field");
-            bytes_array(cc, field);
-            const size_t want = f == sh.path_index ? path_bytes : 32;
-            if (field.size() != want) bad("circuit_inputs: field of the wrong length");
-            for (size_t o = 0; o < want; o += 32) {          // vec_to_f panics on a non-canonical element (utils.rs:33)
-                shp::Fr raw;
-                memcpy(raw.l, field.data() + o, 32);
-                if (raw.geq_p()) bad("circuit_inputs: not a canonical field element");
-            }
-            memcpy(witness_le32 + offset[f], field.data(), want);
-            seen[f] = true;
-        });
-        end_of_input(ic);
-        for (int f = 0; f < sh.n_fields; f++)
-            if (!seen[f]) bad("circuit_inputs: missing field");
-        *n_inputs = total / 32;
+        decode_payload(payload, height, circuit, witness_le32, witness_cap, n_inputs);
     });
 }
 
@@ -320,6 +357,42 @@ int32_t shp_tee_encode_proof_response(int32_t circuit, const uint8_t* proof, siz
         *out_len = body.size();
         SHP_REQUIRE(out && cap >= body.size(), SHP_ERR_INVALID_ARG, "tee_encode_proof_response: buffer too small");
         memcpy(out, body.data(), body.size());
+    });
+}
+
+int32_t shp_tee_decode_payload(const uint8_t* json, size_t len, uint32_t height, int32_t* circuit, uint8_t* witness_le32,
+                               size_t witness_cap, size_t* n_inputs) {
+    return shp::guarded([&] {
+        SHP_REQUIRE(json && circuit && n_inputs, SHP_ERR_INVALID_ARG, "tee_decode_payload: null argument");
+        *circuit = -1; *n_inputs = 0;
+        const std::vector<uint8_t> payload(json, json + len);
+        decode_payload(payload, height, circuit, witness_le32, witness_cap, n_inputs);
+    });
+}
+
+int32_t shp_http_decode_proof_body(const uint8_t* json, size_t len, uint8_t* payload_out, size_t cap, size_t* payload_len) {
+    return shp::guarded([&] {
+        SHP_REQUIRE(json && payload_len, SHP_ERR_INVALID_ARG, "http_decode_proof_body: null argument");
+        Cur c{json, json + len};
+        std::string b64text;
+        bool have = false;
+        object(c, [&](const std::string& k, Cur& cc) {
+            if (k == "payload") {
+                if (have) bad("duplicate field");
+                have = true;
+                b64text = str(cc);
+            } else {
+                skip(cc);
+            }
+        });
+        end_of_input(c);
+        if (!have) bad("missing field `payload`");
+        std::vector<uint8_t> raw;
+        b64_decode(b64text, raw);
+        *payload_len = raw.size();
+        if (!payload_out) return;
+        SHP_REQUIRE(cap >= raw.size(), SHP_ERR_INVALID_ARG, "http_decode_proof_body: buffer too small");
+        memcpy(payload_out, raw.data(), raw.size());
     });
 }
 

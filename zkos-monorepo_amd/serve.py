@@ -233,13 +233,45 @@ async def request(host, port, req):
         writer.close()
 
 
+class BalancedBackend:
+    """several PoolBackends of one circuit type (one per GPU): each request to the pool with the fewest unfinished jobs --
+    what the library's own front does for its pools"""
+
+    def __init__(self, backends):
+        self.backends, self.n_height = list(backends), backends[0].n_height
+
+    def prove(self, wit: bytes, seed: bytes):
+        return min(self.backends, key=lambda b: b.pool.outstanding()).prove(wit, seed)
+
+
+CIRCUIT_BUILDERS = (("Withdraw", "build_withdraw_plan"), ("Deposit", "build_deposit_plan"), ("NewAccount", "build_new_account_plan"))
+
+
+def build_backends(shp, circuits, ctx, params, lanes, circuit_types=("Withdraw", "Deposit", "NewAccount")):
+    """The keys and pools of one GPU, as the reference's build step makes them for every circuit
+    (/root/reference/crates/shielder_bindings/build.rs:19-60: generate_keys_with_min_k over the full SRS).  A circuit
+    whose minimal k is the SRS's own k proves over the full SRS's multiples tables (a downsize to the same k shares
+    them), so Withdraw and Deposit cost one table pair, not three; only NewAccount (2^12) builds a smaller pair."""
+    backends = {}
+    for ctype, builder in CIRCUIT_BUILDERS:
+        if ctype not in circuit_types:
+            continue
+        plan, lay = getattr(circuits, builder)()
+        _, _, pk = shp.ProvingKey.generate_keys_with_min_k(ctx, params, plan)
+        backends[ctype] = PoolBackend(shp.Pool(pk, lanes), lay.height)
+    return backends
+
+
 def main():
     import argparse
     import importlib
-    ap = argparse.ArgumentParser(description="Shielder prover server on one MI355X (TEE wire protocol over TCP)")
+    ap = argparse.ArgumentParser(description="Shielder prover server on the MI355Xs of one node (TEE wire protocol and the "
+                                             "reference's HTTP routes over TCP)")
     ap.add_argument("--port", type=int, default=5000)
-    ap.add_argument("--lanes", type=int, default=16)
-    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=16, help="proving lanes per circuit type and GPU")
+    ap.add_argument("--devices", default="0", help="GPUs to serve from, e.g. 0,1,2,3,4,5,6,7 or `all`: one listener, a pool "
+                                                   "per circuit type on every GPU, each request to the least loaded pool")
+    ap.add_argument("--device", type=int, default=None, help=argparse.SUPPRESS)       # older spelling of --devices N
     ap.add_argument("--ptau", help="path of a snarkjs .ptau file with 2^13 powers (a ceremony SRS: nobody knows tau)")
     ap.add_argument("--insecure-synthetic-srs", action="store_true",
                     help="build the SRS from a trapdoor instead of a ceremony file: whoever knows the trapdoor can forge "
@@ -250,6 +282,10 @@ def main():
     ap.add_argument("--python-frontend", action="store_true",
                     help="serve through this module's asyncio loop instead of the library's own TCP front (shp_server): "
                          "one interpreter thread moves every frame")
+    ap.add_argument("--hw-queues", type=int, default=22, help="GPU_MAX_HW_QUEUES for this process: lanes beyond that many share "
+                                                               "hardware queues (0 = leave the environment alone)")
+    ap.add_argument("--spawn-timeout-ms", type=int, default=0, help="wait for a free queue slot (0 = the reference's 5 s)")
+    ap.add_argument("--run-timeout-ms", type=int, default=0, help="wait for a proof (0 = the reference's 60 s)")
     a = ap.parse_args()
     if not a.ptau and not a.insecure_synthetic_srs:
         ap.error("an SRS is required: --ptau FILE (ceremony powers of tau), or --insecure-synthetic-srs for tests")
@@ -261,22 +297,27 @@ def main():
         tau = a.tau if a.tau is not None else int.from_bytes(os.urandom(32), "little") % R_MOD
     shp = importlib.import_module(__package__ or "zkos-monorepo_amd")
     circuits = importlib.import_module((__package__ or "zkos-monorepo_amd") + ".circuits")
-    shp.prefer_sleeping_waits(3 * a.lanes)                # three pools of a.lanes lanes each
-    ctx = shp.Context(a.device)
-    params = shp.Params.read_ptau(ctx, open(a.ptau, "rb").read()) if a.ptau else shp.Params.synthetic(ctx, 13, tau)
-    backends = {}
-    for ctype, build in (("Withdraw", circuits.build_withdraw_plan), ("Deposit", circuits.build_deposit_plan),
-                         ("NewAccount", circuits.build_new_account_plan)):
-        plan, lay = build()
-        _, _, pk = shp.ProvingKey.generate_keys_with_min_k(ctx, params, plan)      # NewAccount is a 2^12 circuit
-        backends[ctype] = PoolBackend(shp.Pool(pk, a.lanes), lay.height)
+    if a.hw_queues:
+        shp.set_hw_queues(a.hw_queues)
+    if a.device is not None:
+        a.devices = str(a.device)
+    devices = list(range(shp.device_count())) if a.devices == "all" else [int(d) for d in a.devices.split(",")]
+    shp.prefer_sleeping_waits(3 * a.lanes * len(devices))  # three pools of a.lanes lanes on every GPU
+    per_device = []
+    ptau_bytes = open(a.ptau, "rb").read() if a.ptau else None
+    for dev in devices:
+        ctx = shp.Context(dev)
+        params = shp.Params.read_ptau(ctx, ptau_bytes) if ptau_bytes else shp.Params.synthetic(ctx, 13, tau)
+        per_device.append(build_backends(shp, circuits, ctx, params, a.lanes))
 
     if not a.python_frontend:
         # the request loop runs inside the library (csrc/server.hip): this process only holds the keys and waits
         import threading
-        height = max(b.n_height for b in backends.values())
-        srv = shp.NativeServer({ctype: b.pool for ctype, b in backends.items()}, height, port=a.port)
-        print(f"[serve] native front listening on 127.0.0.1:{srv.port}, {a.lanes} lanes per circuit", flush=True)
+        height = max(b.n_height for b in per_device[0].values())
+        pools = {ctype: [bk[ctype].pool for bk in per_device] for ctype in per_device[0]}
+        srv = shp.NativeServer(pools, height, port=a.port, spawn_timeout_ms=a.spawn_timeout_ms, run_timeout_ms=a.run_timeout_ms)
+        print(f"[serve] native front listening on 127.0.0.1:{srv.port}, {a.lanes} lanes per circuit on each of "
+              f"{len(devices)} GPU(s)", flush=True)
         try:
             threading.Event().wait()
         except KeyboardInterrupt:
@@ -284,6 +325,9 @@ def main():
         finally:
             srv.close()
         return
+
+    backends = {ctype: (per_device[0][ctype] if len(per_device) == 1 else BalancedBackend([bk[ctype] for bk in per_device]))
+                for ctype in per_device[0]}
 
     async def run():
         srv = await Server(backends).serve(port=a.port)
