@@ -146,3 +146,20 @@ def test_bench_two_ranks_with_real_pools(batch):
     assert abs(j["value"] - j["config"]["proofs_per_step"] * 2 / (2 * j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
     assert j["config"]["compiled_level"] == 2 and "micro" not in j and "cpu_baseline" not in j
     assert j["setup_s"]["srs_and_tables"] > 0 and j["p50_latency_ms"] > 0
+
+
+def test_ntt_in_29_bit_lazy_arithmetic_matches_oracle():
+    """SHP_NTT29=1 selects the transform's other tile kernel (nine 29-bit limbs, lazy reduction, decimation in time; the
+    switch is read once per process, hence the child): the NTT, coset-extension and no-allocation parity tests and a whole
+    proof run again under it -- every result must stay bit-identical to the oracle's"""
+    b = sys.modules.get("zkos-monorepo_amd.binding")
+    if b is not None and b.Context.created:
+        pytest.skip("this process has already initialised the GPU: it must not start another program")
+    env = dict(os.environ, SHP_NTT29="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          os.path.join(ROOT, "tests", "test_gpu_primitives.py"), os.path.join(ROOT, "tests", "test_zz_no_alloc.py"),
+                          os.path.join(ROOT, "tests", "test_gpu_prover.py"),
+                          "-k", "ntt_matches_oracle or three_pass or coset or noalloc or (proof_bytes and True)"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout

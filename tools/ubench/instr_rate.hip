@@ -61,6 +61,16 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t iters, uint32_t
         } else if (KIND == 12) {  // v_lshrrev_b64
             REP8(asm volatile("v_lshrrev_b64 %0, 3, %0\n v_lshrrev_b64 %1, 3, %1\n v_lshrrev_b64 %2, 3, %2\n v_lshrrev_b64 %3, 3, %3\n"
                               : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3));)
+        } else if (KIND == 14) {  // v_mad_u64_u32 with an SGPR factor and its carry into an SGPR pair (what the compiler emits for q * p_i)
+            REP8(asm volatile("v_mad_u64_u32 %0, s[20:21], %4, %5, %0\n v_mad_u64_u32 %1, s[20:21], %4, %5, %1\n"
+                              "v_mad_u64_u32 %2, s[20:21], %4, %5, %2\n v_mad_u64_u32 %3, s[20:21], %4, %5, %3\n"
+                              : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3) : "v"(a), "s"(seed) : "s20", "s21");)
+        } else if (KIND == 15) {  // v_and_b32 with a literal
+            REP8(asm volatile("v_and_b32 %0, 0x1fffffff, %1\n v_and_b32 %1, 0x1fffffff, %2\n v_and_b32 %2, 0x1fffffff, %3\n v_and_b32 %3, 0x1fffffff, %0\n"
+                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));)
+        } else if (KIND == 16) {  // the carry step of a 29-bit normalisation: v_lshrrev_b32 + v_add_u32
+            REP8(asm volatile("v_lshrrev_b32 %0, 29, %1\n v_add_u32 %1, %1, %0\n v_lshrrev_b32 %2, 29, %3\n v_add_u32 %3, %3, %2\n"
+                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));)
         } else if (KIND == 13) {  // v_mad_u64_u32 whose addend is built from two other registers (mov pair cost)
             REP8(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %1\n v_mad_u64_u32 %1, vcc, %4, %5, %2\n"
                               "v_mad_u64_u32 %2, vcc, %4, %5, %3\n v_mad_u64_u32 %3, vcc, %4, %5, %0\n"
@@ -125,6 +135,10 @@ int main() {
         run<6>("v_fma_f64", w, d, cus, clk);
         run<8>("v_add3_u32", w, d, cus, clk);
         run<11>("v_alignbit_b32", w, d, cus, clk);
+        run<12>("v_lshrrev_b64", w, d, cus, clk);
+        run<14>("v_mad_u64_u32 sgpr", w, d, cus, clk);
+        run<15>("v_and_b32 literal", w, d, cus, clk);
+        run<16>("v_lshrrev_b32 + v_add_u32", w, d, cus, clk);
     }
     return 0;
 }

@@ -236,8 +236,12 @@ int32_t shp_ctx_create(int32_t device, shp_ctx** out) {
             ntt_static_setup(c.get());
         } catch (...) {
             ntt_static_teardown(c.get());
-            for (int d = 0; d < 2; d++)
+            for (int d = 0; d < 2; d++) {
                 if (c->ntt_small[d]) (void)hipFree(c->ntt_small[d]);
+                if (c->ntt_small29_a[d]) (void)hipFree(c->ntt_small29_a[d]);
+                if (c->ntt_small29_b[d]) (void)hipFree(c->ntt_small29_b[d]);
+                if (c->ntt_small29_c[d]) (void)hipFree(c->ntt_small29_c[d]);
+            }
             (void)hipStreamDestroy(c->stream);
             throw;
         }
@@ -250,12 +254,18 @@ int32_t shp_ctx_destroy(shp_ctx* ctx) {
         if (!ctx) return;
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
-        for (int d = 0; d < 2; d++)
+        for (int d = 0; d < 2; d++) {
             if (ctx->ntt_small[d]) (void)hipFree(ctx->ntt_small[d]);
+            if (ctx->ntt_small29_a[d]) (void)hipFree(ctx->ntt_small29_a[d]);
+            if (ctx->ntt_small29_b[d]) (void)hipFree(ctx->ntt_small29_b[d]);
+            if (ctx->ntt_small29_c[d]) (void)hipFree(ctx->ntt_small29_c[d]);
+        }
         for (auto& kv : ctx->ntt_tables)
             for (int d = 0; d < 2; d++) {
                 (void)hipFree(kv.second.lo[d]);
                 (void)hipFree(kv.second.hi[d]);
+                for (int q = 0; q < 2; q++)
+                    if (kv.second.pass[d][q]) (void)hipFree(kv.second.pass[d][q]);
             }
         ctx->ntt_tmp.release();
         ntt_static_teardown(ctx);

@@ -14,10 +14,13 @@ namespace shp {
 //   small[j]   = w_2048^j            j < 1024   (butterflies inside an LDS tile; shared by all sizes)
 //   lo[j]      = w_N^j               j < 2^h    } inter-pass twiddle w_N^e = hi[e >> h] * lo[e & (2^h-1)]
 //   hi[j]      = w_N^(j * 2^h)       j < 2^(log_n - h)
+//   pass[d][p][(kp << lo_bits) | lo] = w_N^((kp * lo) << hi_bits)   the inter-pass twiddles of the non-final pass p in the
+//                                      order its store reads them (domains up to 2^24: adjacent outputs read adjacent entries)
 struct NttTables {
     uint32_t log_n = 0, h = 0;
     Fr* lo[2] = {nullptr, nullptr};      // [0] forward, [1] inverse
     Fr* hi[2] = {nullptr, nullptr};
+    Fr* pass[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     Fr n_inv;
 };
 
@@ -29,6 +32,11 @@ struct shp_ctx {
     int num_cus = 0;
     std::mutex mu;
     shp::Fr* ntt_small[2] = {nullptr, nullptr};          // w_2048^j and its inverse powers
+    // the same powers for the 29-bit lazy tile (SHP_NTT29=1): times 2^5 (Montgomery radix 2^261), split into nine 29-bit
+    // limbs, stored as three planes (limbs 0-3, 4-7, 8) so that a twiddle is two 16-byte loads and one 4-byte load
+    uint4* ntt_small29_a[2] = {nullptr, nullptr};
+    uint4* ntt_small29_b[2] = {nullptr, nullptr};
+    uint32_t* ntt_small29_c[2] = {nullptr, nullptr};
     std::map<uint32_t, shp::NttTables> ntt_tables;
     shp::DevBuf ntt_tmp;                                  // ping-pong buffer of the multi-pass NTT
     // the allocation-free NTT entry point: powers of w_(2^20) split as lo[j] = w^j, hi[j] = w^(1024 j)

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "ctx.hpp"
+#include "lazy29.hip.hpp"
 
 namespace shp {
 
@@ -43,6 +44,7 @@ struct PassParams {
     const Fr* small_tw;
     const Fr* tw_lo;
     const Fr* tw_hi;
+    const Fr* tw_pass;        // this pass's inter-pass twiddles in the order the store reads them: [kp][lo] (null: tw_lo / tw_hi)
     Fr scale, zeta, zeta2;
     const Fr* twist;          // first pass only (null: none)
     uint32_t src_div;         // first pass: transforms per input polynomial (>= 1)
@@ -160,8 +162,10 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
             uint32_t lo = lo_base | v;
             go = ((size_t)hi << (s + p.lo_bits)) | ((size_t)kp << p.lo_bits) | lo;
             uint64_t et = (((uint64_t)kp * lo) << hi_bits) << p.tw_shift;
-            if (et) {
-                // domains up to 2^24 keep every power in one table: one product instead of two
+            if (p.tw_pass) {
+                // the pass's own table: lanes with adjacent outputs read adjacent entries (whole lines, like the data)
+                if (et) val = val * gload(p.tw_pass + (((size_t)kp << p.lo_bits) | lo));
+            } else if (et) {
                 Fr tw = gload(p.tw_lo + (et & ((1u << p.h) - 1)));
                 if (p.h < p.log_n + p.tw_shift) tw = gload(p.tw_hi + (et >> p.h)) * tw;
                 val = val * tw;
@@ -177,6 +181,184 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
             }
         }
         gstore(dst + go, val);
+    }
+}
+
+// ------------------------------------------------------------------ the tile in 29-bit lazy arithmetic (SHP_NTT29=1)
+// The same pass with the tile's arithmetic in nine unsaturated 29-bit limbs (lazy29.hip.hpp): a butterfly's product is
+// 162 multiply-adds with no carry instruction, its sum nine additions and its difference eighteen, with no comparison
+// against p anywhere inside the tile.  Elements stay in the Montgomery radix 2^256 of the rest of the library -- a value
+// x 2^256 is split into limbs as the integer it is -- and every factor the kernel multiplies by (the twiddle tables,
+// 1/n, the zeta pattern) is kept times 2^5, so that Lazy29's product a b 2^-261 leaves the radix where it was; a
+// caller's twist table, which cannot be rescaled, is read shifted by five bits (an unreduced 32 t, allowed as the one
+// lazy operand).
+//
+// Decimation in TIME inside the tile (bit-reversed placement at the load, natural read-out): u = a + w b, d = a - w b + 2p.
+// The product reduces its input, so a value's bound grows by at most 2p per stage (22p after ten stages; decimation in
+// frequency would double it on the sum side of every stage) and the pass's last product -- inter-pass twiddle, 1/n, or
+// the Montgomery one -- brings it below 2p for the one conditional subtraction of the store.  Limbs: a product is
+// normalised (limbs 0..7 below 2^29); a sum adds less than 2^29 to a limb, a difference less than 2^30 (2p is spread as
+// kp_spread(2, 1)), so limbs stay below 2^32 for three stages: every third stage normalises what it stores, and where
+// the product's lazy operand could exceed 2^31 (the third stage of such a group) it is normalised first.
+using R29 = Lazy29<FrParams>;
+using E29 = R29::El;
+
+struct Pass29 {
+    const uint4* small_a;      // w_2048^j 2^5: limbs 0..3
+    const uint4* small_b;      //               limbs 4..7
+    const uint32_t* small_c;   //               limb 8
+    Fr zeta32, zeta2_32;       // first pass with pre_pattern: zeta 2^5, zeta^2 2^5
+    Fr out32[3];               // final pass: the factor of output i, by i mod 3 when post_pattern, [0] otherwise, times 2^5
+};
+
+__device__ __forceinline__ E29 lds29_load(const uint4* lo, const uint4* hi, const uint32_t* top, uint32_t i) {
+    const uint4 a = lo[i], b = hi[i];
+    E29 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = top[i];
+    return r;
+}
+__device__ __forceinline__ void lds29_store(uint4* lo, uint4* hi, uint32_t* top, uint32_t i, const E29& v) {
+    lo[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    hi[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    top[i] = v.l[8];
+}
+// a normalised value below 2^256 as eight 32-bit words
+__device__ __forceinline__ Fr pack29(const E29& t) {
+    Fr r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i = (32 * j) / 29, sft = (32 * j) % 29;
+        uint32_t v = t.l[i] >> sft;
+        v |= t.l[i + 1] << (29 - sft);
+        if (29 - sft + 29 < 32 && i + 2 < 9) v |= t.l[i + 2] << (58 - sft);
+        r.l[j] = v;
+    }
+    return r;
+}
+
+template <int THREADS, int TILE_LOG>
+__global__ __launch_bounds__(THREADS) void ntt29_pass_kernel(PassParams p, Pass29 q) {
+    __shared__ uint4 sh_lo[1 << TILE_LOG];
+    __shared__ uint4 sh_hi[1 << TILE_LOG];
+    __shared__ uint32_t sh_top[1 << TILE_LOG];
+    constexpr l29::L9 KP2 = R29::kp_spread(2, 1);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t poly = p.is_first && p.src_div > 1 ? blockIdx.y / p.src_div : blockIdx.y;
+    const Fr* src = p.src + (size_t)poly * p.src_stride;
+    const Fr* twist = p.is_first && p.twist ? p.twist + ((size_t)(blockIdx.y - poly * p.src_div) << p.log_n) : nullptr;
+    Fr* dst = p.dst + (size_t)blockIdx.y * p.dst_stride;
+    const uint32_t s = p.s, c = p.c;
+    const uint32_t L = 1u << s, V = 1u << c, E = L << c;
+
+    uint32_t hi = 0, lo_base = 0, k1_base = 0, k2 = 0;
+    if (!p.is_final) {
+        uint32_t lo_tiles_log = p.lo_bits - c;
+        hi = tile >> lo_tiles_log;
+        lo_base = (tile & ((1u << lo_tiles_log) - 1)) << c;
+    } else {
+        k2 = tile & ((1u << p.s2) - 1);
+        k1_base = (tile >> p.s2) << c;
+    }
+
+    // ---- load HBM -> limbs -> LDS, sub-transform index bit-reversed (value bound after this block: 1.2 p)
+    for (uint32_t e = tid; e < E; e += THREADS) {
+        size_t gi;
+        uint32_t j, col;
+        if (!p.is_final) {
+            col = e & (V - 1); j = e >> c;
+            gi = ((size_t)hi << (s + p.lo_bits)) | ((size_t)j << p.lo_bits) | (lo_base | col);
+        } else {
+            j = e & (L - 1); col = e >> s;
+            uint32_t k1 = k1_base | col;
+            gi = ((((size_t)k1 << p.s2) | k2) << s) | j;
+        }
+        const uint32_t li = (s ? (__brev(j) >> (32 - s)) : 0) * V + col;
+        E29 val;
+        if (p.is_first && gi >= p.in_len) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) val.l[i] = 0;
+        } else {
+            val = R29::split<0>(gload(src + gi));
+            if (p.is_first && p.pre_pattern) {
+                uint32_t m = (uint32_t)(gi % 3);
+                if (m == 1) val = R29::mul(val, R29::split<0>(q.zeta32));
+                else if (m == 2) val = R29::mul(val, R29::split<0>(q.zeta2_32));
+            }
+            if (twist) val = R29::mul(val, R29::split<5>(gload(twist + gi)));
+        }
+        lds29_store(sh_lo, sh_hi, sh_top, li, val);
+    }
+    __syncthreads();
+
+    // ---- s decimation-in-time stages.  (Requesting a thread's next twiddle one stage ahead, so that its latency passes
+    // behind the sums, stores and barrier, was measured: more instructions, the same time.)
+    for (uint32_t t = 0; t < s; t++) {
+        const uint32_t half = 1u << t;
+        const uint32_t phase = t % 3;                       // stages since the stored values were last normalised
+        for (uint32_t b = tid; b < (E >> 1); b += THREADS) {
+            uint32_t col = b & (V - 1), jb = b >> c;
+            uint32_t grp = jb >> t, pos = jb & (half - 1);
+            uint32_t j0 = (grp << (t + 1)) | pos;
+            uint32_t i0 = j0 * V + col, i1 = (j0 + half) * V + col;
+            E29 a = lds29_load(sh_lo, sh_hi, sh_top, i0);
+            E29 bb = lds29_load(sh_lo, sh_hi, sh_top, i1);
+            if (t) {
+                // limbs below 2^29 + phase 2^30: at phase 2 beyond what the product's lazy operand may hold
+                if (phase == 2) R29::normalise(bb);
+                const uint32_t ti = pos << (10 - t);
+                const uint4 wa = q.small_a[ti], wb = q.small_b[ti];
+                E29 w;
+                w.l[0] = wa.x; w.l[1] = wa.y; w.l[2] = wa.z; w.l[3] = wa.w;
+                w.l[4] = wb.x; w.l[5] = wb.y; w.l[6] = wb.z; w.l[7] = wb.w;
+                w.l[8] = q.small_c[ti];
+                bb = R29::mul(bb, w);                       // pos = 0 multiplies by the Montgomery one: no divergent branch
+            }
+            E29 u, d;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                u.l[i] = a.l[i] + bb.l[i];
+                d.l[i] = a.l[i] + KP2.l[i] - bb.l[i];
+            }
+            if (phase == 2) { R29::normalise(u); R29::normalise(d); }
+            lds29_store(sh_lo, sh_hi, sh_top, i0, u);
+            lds29_store(sh_lo, sh_hi, sh_top, i1, d);
+        }
+        __syncthreads();
+    }
+
+    // ---- LDS -> one reducing product -> eight words -> HBM (natural read-out)
+    const uint32_t hi_bits = p.log_n - s - p.lo_bits;
+    const bool lazy_limbs = s % 3 != 0;                     // the last stage did not normalise what it stored
+    for (uint32_t e = tid; e < E; e += THREADS) {
+        uint32_t col = e & (V - 1), kp = e >> c;
+        E29 val = lds29_load(sh_lo, sh_hi, sh_top, kp * V + col);
+        // limbs below 2^29 + 2 2^30: normalise unless they are known to be below 2^31
+        if (lazy_limbs && s % 3 == 2) R29::normalise(val);
+        size_t go;
+        Fr f;
+        if (!p.is_final) {
+            uint32_t lo = lo_base | col;
+            go = ((size_t)hi << (s + p.lo_bits)) | ((size_t)kp << p.lo_bits) | lo;
+            uint64_t et = (((uint64_t)kp * lo) << hi_bits) << p.tw_shift;
+            f = p.tw_pass ? gload(p.tw_pass + (((size_t)kp << p.lo_bits) | lo)) : gload(p.tw_lo + (et & ((1u << p.h) - 1)));
+            if (!p.tw_pass && p.h < p.log_n + p.tw_shift) {
+                const E29 twv = R29::mul(R29::split<0>(gload(p.tw_hi + (et >> p.h))), R29::split<0>(f));
+                val = R29::mul(val, twv);
+            } else {
+                val = R29::mul(val, R29::split<0>(f));
+            }
+        } else {
+            uint32_t k1 = k1_base | col;
+            go = (size_t)k1 + ((size_t)k2 << p.s1) + ((size_t)kp << (p.s1 + p.s2));
+            const uint32_t m = p.post_pattern ? (uint32_t)(go % 3) : 0;
+            val = R29::mul(val, R29::split<0>(m == 0 ? q.out32[0] : m == 1 ? q.out32[1] : q.out32[2]));
+        }
+        Fr out = pack29(val);
+        out.reduce_once();
+        gstore(dst + go, out);
     }
 }
 
@@ -219,9 +401,17 @@ Fr fr_zeta() {
     return Fr::pow(Fr::from_u64(7), q);
 }
 
-static Fr* upload_powers(const Fr& base, size_t count) {
+// SHP_NTT29=1 (read once per process): the tile runs in 29-bit lazy arithmetic and every table holds its powers times 2^5
+static bool ntt29_mode() {
+    static const bool on = getenv("SHP_NTT29") && atoi(getenv("SHP_NTT29")) == 1;
+    return on;
+}
+static Fr table_first() { return ntt29_mode() ? Fr::from_u64(32) : Fr::one(); }
+
+// v[i] = first * base^i
+static Fr* upload_powers(const Fr& base, size_t count, const Fr& first = table_first()) {
     std::vector<Fr> v(count);
-    Fr acc = Fr::one();
+    Fr acc = first;
     for (size_t i = 0; i < count; i++) {
         v[i] = acc;
         acc = acc * base;
@@ -234,11 +424,11 @@ static Fr* upload_powers(const Fr& base, size_t count) {
 
 // out[i] = base^i for i < count, on the device: thread t raises base to t * 64 by square-and-multiply and walks 64
 // entries from there (the tables of the large domains have up to 2^24 entries; the host loop above takes a second there)
-__global__ void ntt_powers_kernel(Fr base, size_t count, Fr* out) {
+__global__ void ntt_powers_kernel(Fr base, Fr first, size_t count, Fr* out) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t i0 = t * 64;
     if (i0 >= count) return;
-    Fr acc = Fr::one(), sq = base;
+    Fr acc = first, sq = base;
     for (size_t e = i0; e; e >>= 1) {
         if (e & 1) acc = acc * sq;
         sq = Fr::sqr(sq);
@@ -255,11 +445,47 @@ static Fr* device_powers(shp_ctx* ctx, const Fr& base, size_t count) {
     Fr* d = nullptr;
     SHP_HIP(hipMalloc(&d, count * sizeof(Fr)));
     const size_t threads = (count + 63) / 64;
-    hipLaunchKernelGGL(ntt_powers_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, ctx->stream, base, count, d);
+    hipLaunchKernelGGL(ntt_powers_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, ctx->stream, base, table_first(), count, d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(d); SHP_HIP(e); }
     return d;
+}
+
+// table[(kp << lo_bits) | lo] = first * base^((kp * lo) << hi_bits): one thread per lo raises base to lo << hi_bits and walks
+// the 2^s values of kp from there; threads with adjacent lo store adjacent entries
+__global__ void ntt_pass_table_kernel(Fr base, Fr first, uint32_t s, uint32_t lo_bits, uint32_t hi_bits, Fr* out) {
+    const size_t lo = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lo >> lo_bits) return;
+    Fr step = Fr::one(), sq = base;
+    for (size_t e = lo << hi_bits; e; e >>= 1) {
+        if (e & 1) step = step * sq;
+        sq = Fr::sqr(sq);
+    }
+    Fr acc = first;
+    for (size_t kp = 0; kp < ((size_t)1 << s); kp++) {
+        gstore(out + ((kp << lo_bits) | lo), acc);
+        acc = acc * step;
+    }
+}
+
+// the pass structure of a transform: digits (stages per pass) and the tile size they are cut for
+static int ntt_digits(uint32_t log_n, uint32_t digits[3], uint32_t& tile_log) {
+    tile_log = log_n <= 2 * NTT_TILE_SMALL ? NTT_TILE_SMALL : NTT_TILE_LARGE;
+    digits[0] = digits[1] = digits[2] = 0;
+    if (log_n <= tile_log) {
+        digits[0] = log_n;
+        return 1;
+    }
+    if (log_n <= 2 * tile_log) {
+        digits[1] = log_n / 2;
+        digits[0] = log_n - digits[1];
+        return 2;
+    }
+    digits[2] = log_n / 3;
+    digits[1] = (log_n - digits[2]) / 2;
+    digits[0] = log_n - digits[1] - digits[2];
+    return 3;
 }
 
 // tables shared by every size (caller holds ctx->mu)
@@ -270,6 +496,27 @@ static void ntt_small_tables(shp_ctx* ctx) {
     ctx->ntt_small[1] = upload_powers(Fr::inv(w), 1024);
     ctx->zeta = fr_zeta();
     ctx->zeta2 = Fr::sqr(ctx->zeta);
+    if (ntt29_mode()) {
+        for (int d = 0; d < 2; d++) {
+            std::vector<uint4> pa(1024), pb(1024);
+            std::vector<uint32_t> pc(1024);
+            Fr acc = Fr::from_u64(32);
+            const Fr base = d ? Fr::inv(w) : w;
+            for (int i = 0; i < 1024; i++) {
+                const E29 e = R29::split<0>(acc);
+                pa[i] = make_uint4(e.l[0], e.l[1], e.l[2], e.l[3]);
+                pb[i] = make_uint4(e.l[4], e.l[5], e.l[6], e.l[7]);
+                pc[i] = e.l[8];
+                acc = acc * base;
+            }
+            SHP_HIP(hipMalloc(&ctx->ntt_small29_a[d], 1024 * sizeof(uint4)));
+            SHP_HIP(hipMalloc(&ctx->ntt_small29_b[d], 1024 * sizeof(uint4)));
+            SHP_HIP(hipMalloc(&ctx->ntt_small29_c[d], 1024 * sizeof(uint32_t)));
+            SHP_HIP(hipMemcpy(ctx->ntt_small29_a[d], pa.data(), 1024 * sizeof(uint4), hipMemcpyHostToDevice));
+            SHP_HIP(hipMemcpy(ctx->ntt_small29_b[d], pb.data(), 1024 * sizeof(uint4), hipMemcpyHostToDevice));
+            SHP_HIP(hipMemcpy(ctx->ntt_small29_c[d], pc.data(), 1024 * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+    }
 }
 
 const NttTables& ntt_tables_for(shp_ctx* ctx, uint32_t log_n) {
@@ -279,17 +526,40 @@ const NttTables& ntt_tables_for(shp_ctx* ctx, uint32_t log_n) {
     if (it != ctx->ntt_tables.end()) return it->second;
     NttTables t;
     t.log_n = log_n;
-    // Every power in ONE table up to 2^24 points (512 MB per direction at 2^24: HBM has the room and the bandwidth --
-    // the transform uses 5 % of it -- while a second product per element per pass boundary for hi * lo is ALU time);
-    // above that the exponent is split into two table lookups and a product.  SHP_NTT_FULL_TABLE_LOG overrides the limit.
+    // Up to 2^24 points every non-final pass has a table of its own with ONE entry per element it stores, laid out in the
+    // order of the store: [kp][lo] (2^log_n entries for the first pass -- 512 MB per direction at 2^24 -- and 2^(log_n -
+    // digits[0]) for the middle pass of three).  HBM has the room, and one product per element per pass boundary instead
+    // of hi * lo is ALU time saved; the layout matters as much: with all powers in one table indexed by the exponent
+    // (kp * lo) a wave gathered 32-byte entries kp lines apart -- four times the table's bytes in lines fetched, which
+    // held the 2^20..2^24 transforms at the memory system's rate, not the ALU's.  Above 2^24 (SHP_NTT_FULL_TABLE_LOG
+    // overrides the limit) the exponent is split into two small table lookups and a product.
     static const uint32_t full_log = getenv("SHP_NTT_FULL_TABLE_LOG") ? (uint32_t)atoi(getenv("SHP_NTT_FULL_TABLE_LOG")) : 24;
-    t.h = log_n <= full_log ? log_n : (log_n + 1) / 2;
+    t.h = (log_n + 1) / 2;
     Fr w = fr_root_of_unity(log_n);
     Fr wi = Fr::inv(w);
     t.lo[0] = device_powers(ctx, w, (size_t)1 << t.h);
     t.lo[1] = device_powers(ctx, wi, (size_t)1 << t.h);
     t.hi[0] = upload_powers(pow2k(w, t.h), (size_t)1 << (log_n - t.h));
     t.hi[1] = upload_powers(pow2k(wi, t.h), (size_t)1 << (log_n - t.h));
+    if (log_n <= full_log) {
+        uint32_t digits[3], tile_log;
+        const int P = ntt_digits(log_n, digits, tile_log);
+        uint32_t consumed = 0;
+        for (int pass = 0; pass + 1 < P; pass++) {
+            const uint32_t s = digits[pass], lo_bits = log_n - consumed - s, hi_bits = consumed;
+            for (int d = 0; d < 2; d++) {
+                Fr* tab = nullptr;
+                SHP_HIP(hipMalloc(&tab, sizeof(Fr) << (s + lo_bits)));
+                t.pass[d][pass] = tab;
+                const uint32_t threads = 1u << lo_bits;
+                hipLaunchKernelGGL(ntt_pass_table_kernel, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, d ? wi : w,
+                                   table_first(), s, lo_bits, hi_bits, tab);
+            }
+            consumed += s;
+        }
+        SHP_HIP(hipGetLastError());
+        SHP_HIP(hipStreamSynchronize(ctx->stream));
+    }
     t.n_inv = Fr::inv(Fr::from_u64(1ull << log_n));
     return ctx->ntt_tables.emplace(log_n, t).first->second;
 }
@@ -300,22 +570,8 @@ static void ntt_launch_with(shp_ctx* ctx, const NttTables& T, uint32_t tw_shift,
     const size_t N = (size_t)1 << log_n;
     const int dir = o.inverse ? 1 : 0;
 
-    const uint32_t tile_log = log_n <= 2 * NTT_TILE_SMALL ? NTT_TILE_SMALL : NTT_TILE_LARGE;
-    uint32_t digits[3] = {0, 0, 0};
-    int P;
-    if (log_n <= tile_log) {
-        P = 1;
-        digits[0] = log_n;
-    } else if (log_n <= 2 * tile_log) {
-        P = 2;
-        digits[1] = log_n / 2;
-        digits[0] = log_n - digits[1];
-    } else {
-        P = 3;
-        digits[2] = log_n / 3;
-        digits[1] = (log_n - digits[2]) / 2;
-        digits[0] = log_n - digits[1] - digits[2];
-    }
+    uint32_t digits[3], tile_log;
+    const int P = ntt_digits(log_n, digits, tile_log);
     Fr* tmp = tmp_in;
     if (P > 1 && !tmp) {
         std::lock_guard<std::mutex> g(ctx->mu);
@@ -358,12 +614,29 @@ static void ntt_launch_with(shp_ctx* ctx, const NttTables& T, uint32_t tw_shift,
         p.small_tw = ctx->ntt_small[dir];
         p.tw_lo = T.lo[dir];
         p.tw_hi = T.hi[dir];
+        p.tw_pass = pass + 1 < P && tw_shift == 0 ? T.pass[dir][pass] : nullptr;
         if (p.is_first) { p.src = d_in; p.src_stride = in_stride; }
         else { p.src = tmp; p.src_stride = N; }
         if (p.is_final) { p.dst = d_out; p.dst_stride = N; }
         else { p.dst = tmp; p.dst_stride = N; }
         uint32_t tiles = (uint32_t)(N >> (p.s + p.c));
-        if (tile_log == NTT_TILE_SMALL)
+        if (ntt29_mode()) {
+            Pass29 q;
+            q.small_a = ctx->ntt_small29_a[dir];
+            q.small_b = ctx->ntt_small29_b[dir];
+            q.small_c = ctx->ntt_small29_c[dir];
+            const Fr c32 = Fr::from_u64(32);
+            q.zeta32 = ctx->zeta * c32;
+            q.zeta2_32 = ctx->zeta2 * c32;
+            const Fr f0 = o.inverse ? T.n_inv * c32 : c32;          // 1/n, or the Montgomery one: the pass's reducing product
+            q.out32[0] = f0;
+            q.out32[1] = f0 * ctx->zeta2;
+            q.out32[2] = f0 * ctx->zeta;
+            if (tile_log == NTT_TILE_SMALL)
+                hipLaunchKernelGGL((ntt29_pass_kernel<256, NTT_TILE_SMALL>), dim3(tiles, batch), dim3(256), 0, st, p, q);
+            else
+                hipLaunchKernelGGL((ntt29_pass_kernel<512, NTT_TILE_LARGE>), dim3(tiles, batch), dim3(512), 0, st, p, q);
+        } else if (tile_log == NTT_TILE_SMALL)
             hipLaunchKernelGGL((ntt_pass_kernel<256, NTT_TILE_SMALL>), dim3(tiles, batch), dim3(256), 0, st, p);
         else
             hipLaunchKernelGGL((ntt_pass_kernel<512, NTT_TILE_LARGE>), dim3(tiles, batch), dim3(512), 0, st, p);
