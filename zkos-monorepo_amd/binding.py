@@ -144,11 +144,17 @@ class Context:
         sp = C.c_void_p()
         _check(lib().shp_ctx_stream(self.h, C.byref(sp)))
         torch.cuda.set_device(device)
+        self._prev_stream = torch.cuda.current_stream(device)
         self.torch_stream = torch.cuda.ExternalStream(sp.value, device=device)
         torch.cuda.set_stream(self.torch_stream)
 
     def close(self):
         if self.h:
+            # torch must not be left with a current stream that no longer exists (a second context of a process -- one per
+            # GPU in the serve front -- comes and goes while the first one lives on)
+            import torch
+            if torch.cuda.current_stream(self.device) == self.torch_stream:
+                torch.cuda.set_stream(self._prev_stream)
             lib().shp_ctx_destroy(self.h)
             self.h = C.c_void_p()
 

@@ -107,6 +107,33 @@ inline double& wait_us_accum() {
     static thread_local double v = 0;
     return v;
 }
+// A lone proof's host thread does not wait for the STREAM after a kernel whose results it needs, but for the results:
+// the kernel's last workgroup stores them into pinned host memory and then, behind a system-scope fence, a stamp (a
+// launch sequence number) per result.  The host spins on the stamps and goes on as soon as they are there -- the kernel's
+// own end-of-kernel release, its completion signal and the runtime's wait on it (5 to 10 us a round trip, nine round trips
+// a proof) pass while the host already hashes and launches.  Every 2048 spins the stream is asked whether it has drained:
+// a drained stream has made every store visible (and reports a failed kernel), so the wait ends there whatever the stamps say.
+inline void wait_stamps(const uint32_t* stamps, uint32_t count, uint32_t seq, hipStream_t st) {
+    const volatile uint32_t* sp = stamps;
+    uint32_t spins = 0;
+    for (uint32_t i = 0; i < count;) {
+        if (sp[i] == seq) { i++; continue; }
+        if ((++spins & 2047u) == 0) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) SHP_HIP(q);
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+__device__ __forceinline__ void publish_stamp(uint32_t* stamp, uint32_t seq) {
+    __threadfence_system();
+    __hip_atomic_store(stamp, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 inline void sync_stream(hipStream_t st) {
     static const bool trace = getenv("SHP_PHASE_TRACE") != nullptr;
     if (!trace) {

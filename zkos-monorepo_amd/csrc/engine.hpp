@@ -77,9 +77,19 @@ struct MsmWorkspace {
     std::vector<G1Affine> h_aff;
     uint64_t last_adds = 0, last_bytes = 0;
     uint64_t min_waves = 0;     // direct mode: waves a launch should have before chains get longer (0 = default)
+    // direct mode, a lone proof's lane: wait for the sums themselves (stamps in pinned memory) instead of the stream
+    bool poll_results = false;
+    PinnedBuf h_stamp;
+    uint32_t stamp_seq = 0;
+    // the launch in flight between msm_launch_jobs and msm_finish_jobs
+    struct PendJob { G1Affine* h_out; uint32_t msm_base, batch; };
+    std::vector<PendJob> pend;
+    uint32_t pend_total = 0, pend_seq = 0;
+    bool pend_poll = false;
     void release() {
         cnt.release(); start.release(); entries.release(); pf.release(); pl.release(); buckets.release(); out.release();
         wg_hist.release(); binned.release(); cursor.release(); h_out.release(); h_totals.release(); segs.release(); h_segs.release(); seg_cached = 0;
+        h_stamp.release();
         done.release(); done_zeroed = 0;
     }
 };
@@ -130,6 +140,8 @@ struct MsmJob {
 };
 }  // namespace shp
 void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& ws, hipStream_t st);
+void msm_launch_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& ws, hipStream_t st);
+void msm_finish_jobs(shp::MsmWorkspace& ws, hipStream_t st);
 namespace shp {
 // the MSM plan of one of an SRS's two bases: the primary one (built first) may take the larger multiples table
 void msm_create_for_srs(shp_ctx* ctx, const void* d_bases, size_t n, bool primary, shp_msm** out);

@@ -573,6 +573,8 @@ struct DirectArgs {
     G1X* partials;
     uint32_t* done;       // per MSM of the launch: workgroups that have stored their partial sum
     G1X* out;             // per MSM: the sum (may be pinned host memory)
+    uint32_t* stamp;      // per MSM, pinned host memory (null: none): set to `seq` once the sum is stored (wait_stamps)
+    uint32_t seq;
 };
 
 // Sum of one XYZZ point per thread over a 256-thread workgroup; the result is valid in thread 0.
@@ -968,6 +970,7 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
     if (threadIdx.x == 0) {
         a.out[sg.msm_base + m] = sum;
         *done = 0;                                             // ready for the next launch
+        if (a.stamp) publish_stamp(a.stamp + sg.msm_base + m, a.seq);
     }
 }
 
@@ -1132,8 +1135,17 @@ static void normalise_batch(const G1X* in, uint32_t batch, G1Affine* h_out) {
     }
 }
 
-// All jobs in ONE launch of msm_direct_kernel + one of the final sums; synchronises `st`.
+// All jobs in ONE launch of msm_direct_kernel (the final sums included), in two halves so that a caller can queue other
+// work behind the launch before it waits: msm_launch_jobs returns once the kernel is queued, msm_finish_jobs waits for the
+// sums -- for their stamps in pinned memory when the workspace polls (whatever else the stream still holds), for the
+// stream otherwise -- normalises them and hands them out.  One launch per workspace at a time.
 void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& ws, hipStream_t st) {
+    msm_launch_jobs(jobs, n_jobs, ws, st);
+    msm_finish_jobs(ws, st);
+}
+
+void msm_launch_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& ws, hipStream_t st) {
+    SHP_REQUIRE(!ws.pend_total, SHP_ERR_INTERNAL, "msm: the workspace already has a launch in flight");
     SHP_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= shp::MSM_MAX_JOBS, SHP_ERR_INVALID_ARG, "msm: bad job list");
     const shp_msm* m0 = jobs[0].m;
     SHP_REQUIRE(m0 && m0->direct, SHP_ERR_INVALID_ARG, "msm: job list needs direct-table plans");
@@ -1219,20 +1231,40 @@ void msm_run_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace& w
     a.done = ws.done.as<uint32_t>();
     a.out = ws.h_out.as<G1X>();                                // straight into pinned host memory: no copy dispatch
     KernelTimers none, *tm = ws.timers ? ws.timers : &none;
+    const bool poll = ws.poll_results && !tm->enabled;         // (event timing needs the stream drained)
+    a.stamp = nullptr;
+    a.seq = 0;
+    if (poll) {
+        ws.h_stamp.reserve(std::max<size_t>(total, 64) * sizeof(uint32_t));
+        a.stamp = ws.h_stamp.as<uint32_t>();
+        a.seq = ++ws.stamp_seq ? ws.stamp_seq : ++ws.stamp_seq;   // never 0: a fresh buffer may hold anything but is unlikely to hold the next number
+        for (size_t i = 0; i < total; i++) a.stamp[i] = a.seq - 1;
+    }
     tm->begin(KID_MSM_DIRECT, st);
     static const bool lazy29 = !(getenv("SHP_MSM_LAZY29") && atoi(getenv("SHP_MSM_LAZY29")) == 0);
     if (lazy29) hipLaunchKernelGGL(msm_direct_kernel<true>, dim3((uint32_t)busy_wgs, gy), dim3(MSM_THREADS), 0, st, a);
     else hipLaunchKernelGGL(msm_direct_kernel<false>, dim3((uint32_t)busy_wgs, gy), dim3(MSM_THREADS), 0, st, a);
     tm->end(st);
     SHP_HIP(hipGetLastError());
-    shp::sync_stream(st);
-    tm->collect();
-    ws.h_aff.resize(total);
-    normalise_batch(ws.h_out.as<G1X>(), (uint32_t)total, ws.h_aff.data());
-    for (uint32_t k = 0; k < n_jobs; k++)
-        memcpy(jobs[k].h_out, ws.h_aff.data() + segs[k].msm_base, (size_t)jobs[k].batch * sizeof(G1Affine));
+    ws.pend.clear();
+    for (uint32_t k = 0; k < n_jobs; k++) ws.pend.push_back({jobs[k].h_out, segs[k].msm_base, jobs[k].batch});
+    ws.pend_total = (uint32_t)total;
+    ws.pend_poll = poll;
+    ws.pend_seq = a.seq;
     ws.last_adds = visited_all * W;                           // upper bound: one mixed add per non-zero digit
     ws.last_bytes = visited_all * 32 + (uint64_t)m0->n * 64;
+}
+
+void msm_finish_jobs(shp::MsmWorkspace& ws, hipStream_t st) {
+    SHP_REQUIRE(ws.pend_total, SHP_ERR_INTERNAL, "msm: no launch in flight");
+    const uint32_t total = ws.pend_total;
+    ws.pend_total = 0;
+    if (ws.pend_poll) shp::wait_stamps(ws.h_stamp.as<uint32_t>(), total, ws.pend_seq, st);
+    else shp::sync_stream(st);
+    if (ws.timers) ws.timers->collect();
+    ws.h_aff.resize(total);
+    normalise_batch(ws.h_out.as<G1X>(), total, ws.h_aff.data());
+    for (const auto& pj : ws.pend) memcpy(pj.h_out, ws.h_aff.data() + pj.msm_base, (size_t)pj.batch * sizeof(G1Affine));
 }
 
 // ---------------------------------------------------------------- cross-lane combiner (engine.hpp)

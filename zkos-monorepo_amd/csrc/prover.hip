@@ -690,6 +690,8 @@ struct shp_prover {
     hipStream_t st = nullptr;
     bool own_stream = false;
     MsmWorkspace msm_ws;
+    PowTable pow_table = {};               // the opening points squared out (powers_kernel)
+    MsmWorkspace msm_ws_rand;              // a lone proof commits to its random polynomial while the host still runs the witness program
     KernelTimers timers;
     uint64_t proofs_done = 0;
     // device workspace
@@ -744,6 +746,7 @@ struct shp_prover {
     // runtime's slow path and serialise concurrent lanes); bump-allocated, rewound at the start of each proof
     PinnedBuf stage;
     size_t stage_off = 0;
+    uint32_t stamp_seq = 0;          // sequence numbers of the results a lone proof waits for in pinned memory (wait_stamps)
     void* stage_alloc(size_t bytes) {
         const size_t at = (stage_off + 63) & ~(size_t)63;
         SHP_REQUIRE(at + bytes <= stage.cap, SHP_ERR_INTERNAL, "prover: staging arena exhausted");
@@ -756,6 +759,7 @@ struct shp_prover {
         h_rand.release();
         for (void* p : owned) (void)hipFree(p);
         msm_ws.release();
+        msm_ws_rand.release();
         if (h_grid) (void)hipHostFree(h_grid);
         if (own_stream && st) (void)hipStreamDestroy(st);
     }
@@ -767,6 +771,12 @@ static void set_witness_threads(shp_prover* pr, uint32_t threads) {
     pr->wsched.build(pr->pk->plan, threads);
     if (pr->wsched.n_threads > 1 && !pr->wsched.plan.empty())
         pr->wworkers.reset(new WitnessWorkers(pr->wsched.n_threads, pr->pk->plan.n_wscratch));
+}
+
+// SHP_POLL_RESULTS=0: latency lanes wait for the stream, as pool lanes do, instead of spinning on result stamps
+static bool poll_results_enabled() {
+    static const bool on = !(getenv("SHP_POLL_RESULTS") && atoi(getenv("SHP_POLL_RESULTS")) == 0);
+    return on;
 }
 
 static void prover_create_impl(shp_pk* pk, shp_prover** out) {
@@ -819,6 +829,7 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->lk_done = pr->dalloc<uint32_t>(std::max<size_t>(P.lookups.size(), 1));
     SHP_HIP(hipMemset(pr->lk_done, 0, std::max<size_t>(P.lookups.size(), 1) * sizeof(uint32_t)));
     pr->msm_ws.timers = &pr->timers;
+    pr->msm_ws.poll_results = poll_results_enabled();       // a new lane is a latency lane until shp_prover_mode says otherwise
     pr->wscratch.assign(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
     {
         const char* e = getenv("SHP_WITNESS_THREADS");
@@ -961,27 +972,43 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     // drained, the inverses come back as kernel arguments.  Pool lanes keep the inversion on the device (one lane,
     // 55 us, but no extra round trip while fifteen other lanes fill the GPU).
     // diff_points non-null: product p runs over omega^r - diff_points[p] (a and b are not read)
-    auto product_scans = [&](const Fr* a, const Fr* b, uint32_t cnt, const Fr* diff_points = nullptr) -> InvList {
+    // host_points (with diff_points): the same points on the host.  Then nobody waits for the total: the product of
+    // omega^r - p over the whole domain is p^n - 1 (n even), which the host has inverted before the kernel starts.
+    auto product_scans = [&](const Fr* a, const Fr* b, uint32_t cnt, const Fr* diff_points = nullptr,
+                             const Fr* host_points = nullptr) -> InvList {
         InvList il;
         il.n = 0;
-        const bool on_host = !pr->throughput && cnt <= INV_LIST_MAX;
+        const bool closed_form = diff_points && host_points && cnt <= INV_LIST_MAX && n >= 2;
+        const bool on_host = closed_form || (!pr->throughput && cnt <= INV_LIST_MAX);
         Fr* totals = on_host ? (Fr*)pr->stage_alloc(cnt * sizeof(Fr)) : nullptr;
         ScanTotals T;
         T.bpre_a = sc_bpre; T.bsuf_b = sc_bsuf; T.inv_b = sc_inv; T.total_out = totals; T.done = pr->sc_done;
         T.omegas = diff_points ? pk->omegas : nullptr; T.points = diff_points;
+        const bool poll = on_host && !closed_form && !pr->timers.enabled && pr->msm_ws.poll_results;
+        T.stamp = poll ? (uint32_t*)pr->stage_alloc(cnt * sizeof(uint32_t)) : nullptr;
+        T.seq = poll ? (++pr->stamp_seq ? pr->stamp_seq : ++pr->stamp_seq) : 0;
+        for (uint32_t i = 0; poll && i < cnt; i++) T.stamp[i] = T.seq - 1;
         hipLaunchKernelGGL(sce == 1 ? scan_local_kernel<1> : scan_local_kernel<SCAN_E_POOL>, dim3(snb, cnt), dim3(sbs), 0, st, a, b,
                            n, pr->sc_pre, pr->sc_suf, sc_ta, sc_tb, T);
-        if (on_host) {
-            sync_stream(st);
+        if (closed_form) {
+            il.n = cnt;
+            for (uint32_t i = 0; i < cnt; i++) {
+                const Fr tot = Fr::pow_u64(host_points[i], n) - Fr::one();
+                SHP_REQUIRE(!tot.is_zero(), SHP_ERR_INTERNAL, "prove: an opening point lies on the domain");   // probability n 2^-254
+                il.v[i] = Fr::inv(tot);
+            }
+        } else if (on_host) {
+            if (poll) wait_stamps(T.stamp, cnt, T.seq, st);
+            else sync_stream(st);
             il.n = cnt;
             for (uint32_t i = 0; i < cnt; i++) il.v[i] = Fr::inv(totals[i]);
         }
         return il;
     };
     // out[p][r] = 1 / (omega^r - points[p])
-    auto invert_point_diffs = [&](const Fr* points, Fr* out, uint32_t cnt) {
+    auto invert_point_diffs = [&](const Fr* points, const Fr* host_points, Fr* out, uint32_t cnt) {
         pr->timers.begin(KID_BATCH_INVERT, st);
-        const InvList il = product_scans(nullptr, nullptr, cnt, points);
+        const InvList il = product_scans(nullptr, nullptr, cnt, points, host_points);
         hipLaunchKernelGGL(sce == 1 ? batch_invert_apply_kernel<1> : batch_invert_apply_kernel<SCAN_E_POOL>, dim3(snb, cnt),
                            dim3(sbs), 0, st, (const Fr*)nullptr, pk->omegas, points, pr->sc_pre, pr->sc_suf, sc_bpre, sc_bsuf,
                            sc_inv, n, out, il);
@@ -1025,6 +1052,63 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             msm_run_ws(m, pr->msm_ws, scalars, n, n, batch, out, st);
         }
     };
+    // a proof that failed between a launch and its wait leaves the launch behind: drain it
+    if (pr->msm_ws.pend_total || pr->msm_ws_rand.pend_total) {
+        sync_stream(st);
+        pr->msm_ws.pend_total = pr->msm_ws_rand.pend_total = 0;
+    }
+    // Commitments in two halves (msm_launch_jobs / msm_finish_jobs) for a lone proof's lane: work that does not depend on the
+    // next challenge is queued BEHIND the commitment kernel and runs while the host waits for the points (their stamps in
+    // pinned memory, not the stream), normalises and hashes them.  Pool lanes, lanes behind a combiner and profiled lanes
+    // commit in one piece.
+    const bool split_commits = pr->msm_ws.poll_results && !pr->comb && !pr->timers.enabled && srs->msm_gl->direct && srs->msm_g->direct;
+    // P9's transforms: coefficient form, then the nc cosets of the quotient domain, of every column.  (Cut into column
+    // ranges and queued behind the earlier commitments as well -- advice columns are final after P2 -- they filled those
+    // waits, but a two-pass transform launch has a floor of 20 us whatever its size: what the waits gained the smaller
+    // launches lost again, measured.)
+    NttOpts ntt_inv;
+    ntt_inv.inverse = true;
+    NttOpts ntt_ext;                                     // values on the nc cosets of the quotient domain
+    ntt_ext.twist = pk->twist; ntt_ext.twist_count = pk->nc;
+    uint32_t inv_done = 0, ext_done = 0;                 // columns [0, inv_done) have coefficients, [0, ext_done) cosets
+    auto inv_upto = [&](uint32_t c) {
+        if (c <= inv_done) return;
+        ntt_launch(ctx, pr->vals + (size_t)inv_done * n, pr->polys + (size_t)inv_done * n, k, c - inv_done, ntt_inv, st, pr->ntt_tmp);
+        inv_done = c;
+    };
+    auto ext_upto = [&](uint32_t c) {
+        if (c <= ext_done) return;
+        inv_upto(c);
+        ntt_launch(ctx, pr->polys + (size_t)ext_done * n, pr->cos + (size_t)ext_done * ne, k, (c - ext_done) * pk->nc, ntt_ext, st,
+                   pr->ntt_tmp);
+        ext_done = c;
+    };
+    auto commit_launch = [&](MsmWorkspace& ws, shp_msm* m, const Fr* scalars, uint32_t batch, G1Affine* out, const MsmRows* rows = nullptr) {
+        MsmJob job{m, scalars, n, batch, rows ? *rows : MsmRows{n, 0, 0}, out};
+        ws.poll_results = true;
+        msm_launch_jobs(&job, 1, ws, st);
+    };
+    // ---- P7 first: the random polynomial depends on no challenge and not on the witness -- its coefficients (blinding stream
+    // position known up front) are drawn on the device and its commitment runs while the host executes the witness program
+    const uint64_t ctr_rand = (uint64_t)A * nb + A + (uint64_t)L * (2 * nb + 2) + (uint64_t)(S + L) * (bf + 1);
+    G1Affine rand_comm;
+    auto ingest = [&](uint32_t y0, uint32_t rows, uint32_t rows_now_, uint32_t n_inst) {
+        IngestArgs ia;
+        ia.grid = pr->h_grid; ia.vals = V(0); ia.inst = V(I_INST); ia.rand_poly = pr->rand_poly; ia.h_rand = nullptr;
+        ia.n = n; ia.n_adv = A; ia.rows_now = rows_now_; ia.u = u; ia.n_inst = n_inst; ia.y0 = y0;
+        memcpy(ia.key.w, key, 32);
+        ia.counter0 = ctr_rand;
+        if (in.draws && y0 + rows > A + 1) {
+            pr->h_rand.reserve((size_t)n * sizeof(Fr));
+            memcpy(pr->h_rand.p, in.draws + ctr_rand, (size_t)n * sizeof(Fr));
+            ia.h_rand = pr->h_rand.as<Fr>();
+        }
+        hipLaunchKernelGGL(ingest_kernel, dim3(ceil_div(n, 256), rows), dim3(256), 0, st, ia);
+    };
+    if (split_commits) {
+        ingest(A + 1, 1, 0, 0);
+        commit_launch(pr->msm_ws_rand, srs->msm_g, pr->rand_poly, 1, &rand_comm);
+    }
     // ---- P0/P1: witness, blinding rows, instance column
     std::vector<Fr> instances;
     Fr* const grid = pr->h_grid;                        // pinned: [A][n] advice, then the instance column
@@ -1082,25 +1166,21 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     pc.mark("witness+upload");
     // ---- P2: advice commitments.  The random polynomial of P7 depends on no challenge: its
     // coefficients (blinding stream position known up front) and its commitment ride in the same launch.
-    const uint64_t ctr_rand = (uint64_t)A * nb + A + (uint64_t)L * (2 * nb + 2) + (uint64_t)(S + L) * (bf + 1);
-    {
-        // witness rows, instances and the random polynomial reach the device in one dispatch (ingest_kernel)
-        IngestArgs ia;
-        ia.grid = grid; ia.vals = V(0); ia.inst = V(I_INST); ia.rand_poly = pr->rand_poly; ia.h_rand = nullptr;
-        ia.n = n; ia.n_adv = A; ia.rows_now = rows_now; ia.u = u; ia.n_inst = (uint32_t)instances.size();
-        memcpy(ia.key.w, key, 32);
-        ia.counter0 = ctr_rand;
-        if (in.draws) {
-            pr->h_rand.reserve((size_t)n * sizeof(Fr));
-            memcpy(pr->h_rand.p, in.draws + ctr_rand, (size_t)n * sizeof(Fr));
-            ia.h_rand = pr->h_rand.as<Fr>();
-        }
-        hipLaunchKernelGGL(ingest_kernel, dim3(ceil_div(n, 256), A + 2), dim3(256), 0, st, ia);
-    }
     std::vector<G1Affine> pts(std::max<uint32_t>({A + 1, 2 * L, S + L + 1, P.degree}));
     const MsmRows adv_rows{rows_now, u, n - u};       // assigned rows + blinding rows; the rest is zero
-    commit(srs->msm_gl, V(0), A, pts.data(), &adv_rows, srs->msm_g, pr->rand_poly, 1);
-    const G1Affine rand_comm = pts[A];
+    if (split_commits) {
+        // witness rows and instances in one dispatch; the random polynomial is on its way already
+        ingest(0, A + 1, rows_now, (uint32_t)instances.size());
+        commit_launch(pr->msm_ws, srs->msm_gl, V(0), A, pts.data(), &adv_rows);
+        msm_finish_jobs(pr->msm_ws_rand, st);
+        msm_finish_jobs(pr->msm_ws, st);
+    } else {
+        // witness rows, instances and the random polynomial reach the device in one dispatch (ingest_kernel), and the random
+        // polynomial's commitment rides in the advice columns' launch
+        ingest(0, A + 2, rows_now, (uint32_t)instances.size());
+        commit(srs->msm_gl, V(0), A, pts.data(), &adv_rows, srs->msm_g, pr->rand_poly, 1);
+        rand_comm = pts[A];
+    }
     for (uint32_t c = 0; c < A; c++) tr.write_point(pts[c].x, pts[c].y);
     const Fr theta = tr.squeeze();
 
@@ -1164,7 +1244,12 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         lp.blinds = lk_blinds; lp.err = herr; lp.done = pr->lk_done;
         hipLaunchKernelGGL(lookup_flags_kernel, dim3(ceil_div(u, nt), L), dim3(nt), 0, st, pr->sort_out, pr->sort_out + n,
                            (size_t)2 * n, u, n, pr->rank, lp);
-        commit(srs->msm_gl, V(I_PIN), 2 * L, pts.data());                 // the MSM run synchronises the stream
+        if (split_commits) {
+            commit_launch(pr->msm_ws, srs->msm_gl, V(I_PIN), 2 * L, pts.data());
+            msm_finish_jobs(pr->msm_ws, st);
+        } else {
+            commit(srs->msm_gl, V(I_PIN), 2 * L, pts.data());             // the MSM run synchronises the stream
+        }
         for (uint32_t l = 0; l < L; l++)
             SHP_REQUIRE(herr[l] == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
         for (uint32_t i = 0; i < 2 * L; i++) tr.write_point(pts[i].x, pts[i].y);
@@ -1205,19 +1290,22 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     SHP_REQUIRE(ctr == ctr_rand, SHP_ERR_INTERNAL, "prove: blinding stream position of the random polynomial");
     ctr += n;
     ctr += 1;
-    commit(srs->msm_gl, V(I_PZ), S + L, pts.data());
+    // ---- P9 (coefficient forms and cosets of everything committed so far + the instance column) needs no challenge: for
+    // a lone proof it is queued behind the grand products' commitment and runs while the host waits for those points
+    auto transforms = [&] { ext_upto(NV + 1); };
+    if (split_commits && S + L) {
+        commit_launch(pr->msm_ws, srs->msm_gl, V(I_PZ), S + L, pts.data());
+        transforms();
+        msm_finish_jobs(pr->msm_ws, st);
+    } else {
+        commit(srs->msm_gl, V(I_PZ), S + L, pts.data());
+    }
     for (uint32_t i = 0; i < S + L; i++) tr.write_point(pts[i].x, pts[i].y);
     tr.write_point(rand_comm.x, rand_comm.y);
     pc.mark("products_msm");
     // ---- P8
     const Fr y = tr.squeeze();
-    // ---- P9: coefficient forms and cosets of everything committed so far (+ instance column)
-    NttOpts inv;
-    inv.inverse = true;
-    NttOpts ext;                                         // values on the nc cosets of the quotient domain
-    ext.twist = pk->twist; ext.twist_count = pk->nc;
-    ntt_launch(ctx, pr->vals, pr->polys, k, NV + 1, inv, st, pr->ntt_tmp);
-    ntt_launch(ctx, pr->polys, pr->cos, k, (NV + 1) * pk->nc, ext, st, pr->ntt_tmp);
+    if (!(split_commits && S + L)) transforms();
     // ---- P10: quotient
     const uint32_t ebs = std::min<uint32_t>(256, n);      // element-wise kernels over the quotient domain (n >= 64)
     if (pk->quot_fn) {
@@ -1294,7 +1382,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     }
     // per-coset interpolants, then the nc x nc solve per coefficient: the quotient pieces [nc][n] (in the buffer
     // the lookup compression no longer needs)
-    ntt_launch(ctx, pr->h, pr->h, k, pk->nc, inv, st, pr->ntt_tmp);
+    ntt_launch(ctx, pr->h, pr->h, k, pk->nc, ntt_inv, st, pr->ntt_tmp);
     Fr* const hp = pr->aux_ext;
     hipLaunchKernelGGL(coset_combine_kernel, dim3(ceil_div(n, 256), pk->nc), dim3(256), 0, st, pr->h, pk->cinv, pk->vinv,
                        pk->nc, n, hp);
@@ -1321,8 +1409,19 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         // lane: 16 consecutive powers per thread (exponentiation + 16 products: 2.3 products per power instead of 20)
         const uint32_t per = pr->throughput ? 16 : 1;
         const Fr xn = Fr::pow_u64(x, n);                    // the extra grid row combines the quotient pieces into hx
+        // a lone proof: the host squares every point out (k squarings each) so that a thread's power is a product over
+        // the set bits of its index
+        PowTable& sq = pr->pow_table;                       // 3.5 KB passed by value; its unused entries are never read
+        uint32_t bits = 0;
+        if (!pr->throughput && k <= POW_TABLE_BITS && points.size() <= POW_TABLE_POINTS) {
+            bits = k;
+            for (size_t p = 0; p < points.size(); p++) {
+                Fr v = points[p];
+                for (uint32_t b = 0; b < k; b++) { sq.v[p][b] = v; v = Fr::sqr(v); }
+            }
+        }
         hipLaunchKernelGGL(powers_kernel, dim3(ceil_div(ceil_div(n, per), 256), (uint32_t)points.size() + 1), dim3(256), 0, st,
-                           d_points, (uint32_t)points.size(), n, per, pr->pw, (const Fr*)hp, npieces, xn, pr->hx);
+                           d_points, (uint32_t)points.size(), n, per, pr->pw, (const Fr*)hp, npieces, xn, pr->hx, sq, bits);
     }
     // the eval list in proof order, then h(x) (needed only for the opening argument)
     std::vector<EvalJob> jobs;
@@ -1365,11 +1464,20 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     }
     // the evaluations land in the pinned arena directly (one store per job over PCIe, no copy dispatch)
     Fr* const evals = (Fr*)pr->stage_alloc(jobs.size() * sizeof(Fr));
-    hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)jobs.size()), dim3(EVAL_THREADS), 0, st, pr->jobs, pr->pw, n, evals);
+    const bool poll_evals = pr->msm_ws.poll_results && !pr->timers.enabled;
+    uint32_t* const eval_stamp = poll_evals ? (uint32_t*)pr->stage_alloc(jobs.size() * sizeof(uint32_t)) : nullptr;
+    const uint32_t eval_seq = poll_evals ? (++pr->stamp_seq ? pr->stamp_seq : ++pr->stamp_seq) : 0;
+    for (size_t i = 0; poll_evals && i < jobs.size(); i++) eval_stamp[i] = eval_seq - 1;
+    hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)jobs.size()), dim3(EVAL_THREADS), 0, st, pr->jobs, pr->pw, n, evals, eval_stamp,
+                       eval_seq);
     // Lagrange values of hx and the random polynomial for the evaluation-form opening
     NttOpts fwd;
     ntt_launch(ctx, pr->hx, pr->lag2, k, 2, fwd, st, pr->ntt_tmp);   // out of place: hx | rand_poly are adjacent
-    sync_stream(st);
+    // 1 / (omega^r - point) for every opening point: it depends on x alone, so it is queued here, behind the evaluations,
+    // and runs while the host hashes them and prepares the opening argument
+    invert_point_diffs(d_points, points.data(), pr->dinv, (uint32_t)points.size());
+    if (poll_evals) wait_stamps(eval_stamp, (uint32_t)jobs.size(), eval_seq, st);
+    else sync_stream(st);
     std::map<std::pair<PolyKey, int32_t>, Fr> ev;
     for (size_t i = 0; i < jobs.size(); i++) ev[job_key[i]] = evals[i];
     for (size_t i = 0; i < n_proof_evals; i++) tr.write_scalar(evals[i]);
@@ -1427,7 +1535,6 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         SHP_HIP(hipMemcpyAsync(pr->shp_args, blk, sizeof(sa) + lin.size() * sizeof(LincombArgs), hipMemcpyHostToDevice, st));
     }
     hipLaunchKernelGGL(lincomb_kernel, dim3(ceil_div(n, 256), (uint32_t)sets.size()), dim3(256), 0, st, pr->lin, n, pr->fsets);
-    invert_point_diffs(d_points, pr->dinv, (uint32_t)points.size());
     hipLaunchKernelGGL(shplonk_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals);
     commit(srs->msm_gl, pr->wvals, 1, pts.data());
     tr.write_point(pts[0].x, pts[0].y);
@@ -1458,7 +1565,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     wp.c1 = zt * d0inv;
     wp.n_sets = sa.n_sets; wp.f = pr->fsets; wp.w = pr->wvals; wp.minv = pr->mdiff;
     const Fr* d_mu = (const Fr*)staged(&mu, sizeof(Fr));
-    invert_point_diffs(d_mu, pr->mdiff, 1);
+    invert_point_diffs(d_mu, &mu, pr->mdiff, 1);
     hipLaunchKernelGGL(shplonk_wp_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, wp, n, pr->wvals + n);
     commit(srs->msm_gl, pr->wvals + n, 1, pts.data());
     tr.write_point(pts[0].x, pts[0].y);
@@ -1739,6 +1846,7 @@ int32_t shp_prover_mode(shp_prover* p, uint32_t mode) {
         static const uint64_t tp_waves = getenv("SHP_TP_MIN_WAVES") ? (uint64_t)atol(getenv("SHP_TP_MIN_WAVES")) : 512;
         p->msm_ws.min_waves = mode ? tp_waves : 0;
         p->throughput = mode != 0;
+        p->msm_ws.poll_results = !mode && poll_results_enabled();   // pool lanes sleep in their stream waits instead
         if (mode) set_witness_threads(p, 1);
     });
 }

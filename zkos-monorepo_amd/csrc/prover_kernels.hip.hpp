@@ -195,11 +195,12 @@ struct IngestArgs {
     Fr* rand_poly;
     const Fr* h_rand;        // pinned host memory or null
     uint32_t n, n_adv, rows_now, u, n_inst;
+    uint32_t y0;             // first grid row of this launch: rows 0 .. n_adv - 1 advice, n_adv instances, n_adv + 1 random polynomial
     ChaKey key;
     uint64_t counter0;
 };
 __global__ void ingest_kernel(IngestArgs a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y + a.y0;
     if (y < a.n_adv) {
         const uint32_t moved = a.rows_now + (a.n - a.u);
         if (i >= moved) return;
@@ -336,6 +337,8 @@ struct ScanTotals {          // what the last workgroup of a product does with t
     // non-null: the factors of product p are omega^r - points[p] (the denominators of the SHPLONK quotients), formed
     // here instead of being read from a and b
     const Fr *omegas, *points;
+    uint32_t* stamp;         // with total_out, pinned host memory (null: none): stamp[p] = seq once total_out[p] is stored
+    uint32_t seq;
 };
 // grid (n / (bs E), cnt), bs = blockDim.x = min(256, n / E).  Thread `slot` of product p owns elements [slot E, slot E + E):
 // pre_a[p][slot] = product of a over the workgroup's elements before them, suf_b[p][slot] = product of b over the
@@ -400,6 +403,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_local_kernel(const Fr* a, c
     __threadfence();
     if (t == 0) T.done[blockIdx.y] = 0;
     scan_totals_body(tot_a, tot_b, gridDim.x, T.bpre_a, T.bsuf_b, T.inv_b, T.total_out, blockIdx.y, sh_tot);
+    // (thread 0 stored the total: its own fence orders the stamp behind it)
+    if (t == 0 && T.total_out && T.stamp) publish_stamp(T.stamp + blockIdx.y, T.seq);
 }
 
 // The threads of one workgroup (256, or fewer when the product has one block) for product p, nb <= 256 block totals.
@@ -870,8 +875,13 @@ __global__ void coset_combine_kernel(const Fr* q, const Fr* cinv, const Fr* vinv
 // pw[p][i] = point_p^i
 // the row of blockIdx.y == n_points forms hx = sum_i x^(n i) piece_i instead (Horner over the quotient pieces): the two
 // are independent and share a dispatch
+// sq (bits > 0): sq.v[p][b] = point_p^(2^b), b < bits, squared out by the host and passed by value: a thread's first
+// power is then the product over the set bits of its index -- at most `bits` dependent products, six or seven on
+// average, where square-and-multiply from the point itself chains `bits` squarings and as many products
+constexpr uint32_t POW_TABLE_POINTS = 8, POW_TABLE_BITS = 14;
+struct PowTable { Fr v[POW_TABLE_POINTS][POW_TABLE_BITS]; };
 __global__ void powers_kernel(const Fr* points, uint32_t n_points, uint32_t n, uint32_t per, Fr* pw, const Fr* pieces,
-                              uint32_t n_pieces, Fr xn, Fr* hx) {
+                              uint32_t n_pieces, Fr xn, Fr* hx, PowTable sq, uint32_t bits) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t p = blockIdx.y;
     if (p == n_points) {
@@ -885,7 +895,14 @@ __global__ void powers_kernel(const Fr* points, uint32_t n_points, uint32_t n, u
     uint32_t i0 = t * per;
     if (i0 >= n) return;
     Fr x = ld(points + p);
-    Fr acc = Fr::pow_u64(x, i0);
+    Fr acc;
+    if (bits) {
+        acc = Fr::one();
+        for (uint32_t b = 0; b < bits; b++)
+            if ((i0 >> b) & 1u) acc = acc * sq.v[p][b];
+    } else {
+        acc = Fr::pow_u64(x, i0);
+    }
     Fr* dst = pw + (size_t)p * n;
     for (uint32_t j = 0; j < per && i0 + j < n; j++) {
         st(dst + i0 + j, acc);
@@ -899,7 +916,9 @@ struct EvalJob { const Fr* poly; uint32_t point; uint32_t pad; };
 // 1024 threads per evaluation: at n = 8192 eight products per thread and a shuffle + LDS reduction (a lone proof's
 // 59 evaluations are 59 workgroups -- the per-thread chain is what the kernel's duration is made of)
 constexpr int EVAL_THREADS = 1024;
-__global__ __launch_bounds__(EVAL_THREADS) void eval_kernel(const EvalJob* jobs, const Fr* pw, uint32_t n, Fr* out) {
+// stamp (pinned host memory, null: none): stamp[job] = seq once out[job] is stored -- what a lone proof's host waits for
+__global__ __launch_bounds__(EVAL_THREADS) void eval_kernel(const EvalJob* jobs, const Fr* pw, uint32_t n, Fr* out, uint32_t* stamp,
+                                                            uint32_t seq) {
     __shared__ Fr sh[EVAL_THREADS / 64];
     const EvalJob jb = jobs[blockIdx.x];
     const Fr* w = pw + (size_t)jb.point * n;
@@ -913,6 +932,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_kernel(const EvalJob* jobs,
         Fr s = sh[0];
         for (int k = 1; k < EVAL_THREADS / 64; k++) s = s + sh[k];
         st(out + blockIdx.x, s);
+        if (stamp) publish_stamp(stamp + blockIdx.x, seq);
     }
 }
 
