@@ -10,6 +10,7 @@
 // modular product worth its operand shuffling (BASELINE.json north_star).
 #pragma once
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -186,16 +187,7 @@ struct alignas(16) Fp {
         r.reduce_once();     // p < 2^254: no carry out of limb 7
         return r;
 #else
-        Fp r;
-        uint64_t c = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            c += (uint64_t)a.l[i] + b.l[i];
-            r.l[i] = (uint32_t)c;
-            c >>= 32;
-        }
-        r.reduce_once();     // p < 2^254: no carry out of limb 7
-        return r;
+        return add_host64(a, b);
 #endif
     }
     static SHP_HD Fp sub(const Fp& a, const Fp& b) {
@@ -239,23 +231,7 @@ struct alignas(16) Fp {
             : "vcc");
         return r;
 #else
-        Fp r;
-        uint64_t bw = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint64_t d = (uint64_t)a.l[i] - b.l[i] - bw;
-            r.l[i] = (uint32_t)d;
-            bw = (d >> 32) & 1;
-        }
-        uint32_t mask = (uint32_t)0 - (uint32_t)bw;
-        uint64_t c = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            c += (uint64_t)r.l[i] + (PR::p(i) & mask);
-            r.l[i] = (uint32_t)c;
-            c >>= 32;
-        }
-        return r;
+        return sub_host64(a, b);
 #endif
     }
     static SHP_HD Fp neg(const Fp& a) {
@@ -289,42 +265,98 @@ struct alignas(16) Fp {
 #endif
     }
 #if !defined(__HIP_DEVICE_COMPILE__)
-    // host path of the same CIOS product on 4 x u64 limbs (the driver's transcript / witness work)
+    // Host arithmetic on 4 x u64 limbs (the driver's witness program, transcript and point normalisation run on it: a
+    // lone proof waits for three dependent Poseidon2 permutations of ~900 products each before its first kernel).  On a
+    // little-endian host the eight 32-bit limbs ARE four 64-bit ones; modulus and -p^-1 mod 2^64 are compile-time constants.
+    static constexpr uint64_t p64(int i) { return (uint64_t)PR::p(2 * i) | ((uint64_t)PR::p(2 * i + 1) << 32); }
+    static constexpr uint64_t inv64() {
+        // -p^-1 mod 2^64 from the 32-bit constant by one Newton step: x' = x (2 + p x) keeps x = -p^-1 and doubles the bits
+        const uint64_t x = (uint64_t)PR::INV;
+        return x * (2 + p64(0) * x);
+    }
+    // t (+ 2^256 t4) -> t - p where t >= p; the value is below 2p
+    static inline void reduce_once64(uint64_t t[4]) {
+        typedef unsigned __int128 u128;
+        uint64_t d[4];
+        u128 bw = 0;
+        for (int i = 0; i < 4; i++) {
+            const u128 x = (u128)t[i] - p64(i) - (uint64_t)bw;
+            d[i] = (uint64_t)x;
+            bw = (x >> 64) & 1;
+        }
+        if (!bw) { t[0] = d[0]; t[1] = d[1]; t[2] = d[2]; t[3] = d[3]; }
+    }
+    // CIOS, product and reduction interleaved limb by limb; a fifth word keeps the one extra bit a raw (unreduced
+    // 256-bit) operand can produce between iterations
     static inline Fp mul_host64(const Fp& a, const Fp& b) {
         typedef unsigned __int128 u128;
-        uint64_t A[4], Bv[4], P[4], t[5] = {0, 0, 0, 0, 0};
+        uint64_t A[4], B[4];
+        memcpy(A, a.l, 32);
+        memcpy(B, b.l, 32);
+        constexpr uint64_t P0 = p64(0), P1 = p64(1), P2 = p64(2), P3 = p64(3), INV = inv64();
+        uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#pragma GCC unroll 4
         for (int i = 0; i < 4; i++) {
-            A[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
-            Bv[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
-            P[i] = (uint64_t)PR::p(2 * i) | ((uint64_t)PR::p(2 * i + 1) << 32);
+            const uint64_t bi = B[i];
+            u128 c = (u128)A[0] * bi + t0;
+            const uint64_t m = (uint64_t)c * INV;
+            u128 r = (u128)m * P0 + (uint64_t)c;                       // low word becomes zero
+            c = (u128)A[1] * bi + t1 + (uint64_t)(c >> 64);
+            r = (u128)m * P1 + (uint64_t)c + (uint64_t)(r >> 64);
+            t0 = (uint64_t)r;
+            c = (u128)A[2] * bi + t2 + (uint64_t)(c >> 64);
+            r = (u128)m * P2 + (uint64_t)c + (uint64_t)(r >> 64);
+            t1 = (uint64_t)r;
+            c = (u128)A[3] * bi + t3 + (uint64_t)(c >> 64);
+            r = (u128)m * P3 + (uint64_t)c + (uint64_t)(r >> 64);
+            t2 = (uint64_t)r;
+            const u128 top = (u128)t4 + (uint64_t)(c >> 64) + (uint64_t)(r >> 64);
+            t3 = (uint64_t)top;
+            t4 = (uint64_t)(top >> 64);
         }
-        // -p^-1 mod 2^64 from the 32-bit constant by one Newton step
-        const uint64_t p0 = P[0];
-        uint64_t inv = (uint64_t)PR::INV;                // -p^-1 mod 2^32
-        inv = inv * (2 + p0 * inv);                      // x' = x(2 + p x) keeps x = -p^-1 and doubles the bits
+        uint64_t t[4] = {t0, t1, t2, t3};          // a b < p R leaves t4 = 0 and t < 2p
+        reduce_once64(t);
+        Fp out;
+        memcpy(out.l, t, 32);
+        return out;
+    }
+    static inline Fp add_host64(const Fp& a, const Fp& b) {
+        typedef unsigned __int128 u128;
+        uint64_t A[4], B[4], t[4];
+        memcpy(A, a.l, 32);
+        memcpy(B, b.l, 32);
+        u128 c = 0;
         for (int i = 0; i < 4; i++) {
-            u128 c = 0;
-            for (int j = 0; j < 4; j++) {
-                c += (u128)A[j] * Bv[i] + t[j];
-                t[j] = (uint64_t)c;
-                c >>= 64;
-            }
-            u128 top = (u128)t[4] + c;
-            uint64_t m = t[0] * inv;
-            c = ((u128)m * P[0] + t[0]) >> 64;
-            for (int j = 1; j < 4; j++) {
-                c += (u128)m * P[j] + t[j];
-                t[j - 1] = (uint64_t)c;
-                c >>= 64;
-            }
-            top += c;
-            t[3] = (uint64_t)top;
-            t[4] = (uint64_t)(top >> 64);
+            c += (u128)A[i] + B[i];
+            t[i] = (uint64_t)c;
+            c >>= 64;
         }
-        Fp r;
-        for (int i = 0; i < 4; i++) { r.l[2 * i] = (uint32_t)t[i]; r.l[2 * i + 1] = (uint32_t)(t[i] >> 32); }
-        r.reduce_once();
-        return r;
+        reduce_once64(t);                          // p < 2^254: no carry out of the top limb
+        Fp out;
+        memcpy(out.l, t, 32);
+        return out;
+    }
+    static inline Fp sub_host64(const Fp& a, const Fp& b) {
+        typedef unsigned __int128 u128;
+        uint64_t A[4], B[4], t[4];
+        memcpy(A, a.l, 32);
+        memcpy(B, b.l, 32);
+        u128 bw = 0;
+        for (int i = 0; i < 4; i++) {
+            const u128 x = (u128)A[i] - B[i] - (uint64_t)bw;
+            t[i] = (uint64_t)x;
+            bw = (x >> 64) & 1;
+        }
+        const uint64_t mask = (uint64_t)0 - (uint64_t)bw;       // + p where the subtraction borrowed
+        u128 c = 0;
+        for (int i = 0; i < 4; i++) {
+            c += (u128)t[i] + (p64(i) & mask);
+            t[i] = (uint64_t)c;
+            c >>= 64;
+        }
+        Fp out;
+        memcpy(out.l, t, 32);
+        return out;
     }
 #endif
     static SHP_HD Fp sqr(const Fp& a) { return mul(a, a); }

@@ -1463,6 +1463,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         pr->jobs_uploaded = true;
     }
     // the evaluations land in the pinned arena directly (one store per job over PCIe, no copy dispatch)
+    pc.mark("evals_host");
     Fr* const evals = (Fr*)pr->stage_alloc(jobs.size() * sizeof(Fr));
     const bool poll_evals = pr->msm_ws.poll_results && !pr->timers.enabled;
     uint32_t* const eval_stamp = poll_evals ? (uint32_t*)pr->stage_alloc(jobs.size() * sizeof(uint32_t)) : nullptr;
@@ -1528,13 +1529,15 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         nu_pow = nu_pow * nu;
     }
     sa.f = pr->fsets; sa.dinv = pr->dinv; sa.omegas = pk->omegas;
+    pc.mark("W_host");
     {                                                       // both argument blocks in one upload
         uint8_t* blk = (uint8_t*)pr->stage_alloc(sizeof(sa) + lin.size() * sizeof(LincombArgs));
         memcpy(blk, &sa, sizeof(sa));
         memcpy(blk + sizeof(sa), lin.data(), lin.size() * sizeof(LincombArgs));
         SHP_HIP(hipMemcpyAsync(pr->shp_args, blk, sizeof(sa) + lin.size() * sizeof(LincombArgs), hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL(lincomb_kernel, dim3(ceil_div(n, 256), (uint32_t)sets.size()), dim3(256), 0, st, pr->lin, n, pr->fsets);
+    hipLaunchKernelGGL(lincomb_kernel, dim3(ceil_div(n, 64), (uint32_t)sets.size()), dim3(pr->throughput ? 64 : 256), 0, st, pr->lin, n,
+                       pr->fsets);
     hipLaunchKernelGGL(shplonk_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals);
     commit(srs->msm_gl, pr->wvals, 1, pts.data());
     tr.write_point(pts[0].x, pts[0].y);

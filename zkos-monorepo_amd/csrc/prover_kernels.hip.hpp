@@ -704,7 +704,6 @@ __device__ __forceinline__ void lookup_permute_body(const Fr* a_all, const Fr* t
                                                     const uint32_t* flags_all, const Fr* blinds, uint32_t* err, uint32_t l,
                                                     uint32_t* sh /* [1024] */) {
     const uint32_t t = threadIdx.x, nt = blockDim.x;
-    const Fr* a = a_all + (size_t)l * sstride;
     const Fr* tb = tb_all + (size_t)l * sstride;
     Fr* pin = pin_all + (size_t)l * pstride;
     Fr* ptab = ptab_all + (size_t)l * pstride;
@@ -724,14 +723,11 @@ __device__ __forceinline__ void lookup_permute_body(const Fr* a_all, const Fr* t
     uint32_t rep_off = block_scan_u32_excl(nrep, sh, t, nt, &tot_rep);
     uint32_t keep_off = block_scan_u32_excl(nkeep, sh, t, nt, &tot_keep);
     if (t == 0) err[l] = (any_bad ? 1u : 0u) | (tot_rep != tot_keep ? 2u : 0u);
-    // list the repeated rows; write first occurrences
+    // list the repeated rows (the permuted input, and the table entries of first occurrences, were written by the flag
+    // pass of every workgroup: only what needs the prefix sums is left to this one)
     uint32_t q = rep_off;
-    for (uint32_t i = r0; i < r1; i++) {
-        const Fr am = Fr::from_raw(ld(a + i));
-        st(pin + i, am);
-        if (fl[i] & 1u) st(ptab + i, am);
-        else rep[q++] = i;
-    }
+    for (uint32_t i = r0; i < r1; i++)
+        if (!(fl[i] & 1u)) rep[q++] = i;
     __threadfence_block();
     __syncthreads();
     // leftover table entries (ascending) go to the repeated rows taken from the END
@@ -773,6 +769,10 @@ __global__ __launch_bounds__(1024) void lookup_flags_kernel(const Fr* a_all, con
         const bool tfirst = i == 0 || raw_cmp(ld(tb + i - 1), ti) != 0;
         if (!(tfirst && bsearch_raw(a, u, ti))) f |= 4u;
         flags_all[(size_t)l * n + i] = f;
+        // the permuted input is the sorted input; where a value occurs first, the permuted table repeats it
+        const Fr am = Fr::from_raw(ai);
+        st(pa.pin_all + (size_t)l * pa.pstride + i, am);
+        if (f & 1u) st(pa.ptab_all + (size_t)l * pa.pstride + i, am);
     }
     __threadfence();
     __syncthreads();
@@ -922,8 +922,20 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_kernel(const EvalJob* jobs,
     __shared__ Fr sh[EVAL_THREADS / 64];
     const EvalJob jb = jobs[blockIdx.x];
     const Fr* w = pw + (size_t)jb.point * n;
+    // four coefficient / power pairs requested before the first product (a thread's eight pairs at n = 8192 would
+    // otherwise be eight memory latencies in a row)
     Fr acc = Fr::zero();
-    for (uint32_t i = threadIdx.x; i < n; i += EVAL_THREADS) acc = acc + ld(jb.poly + i) * ld(w + i);
+    uint32_t i = threadIdx.x;
+    for (; i + 3 * EVAL_THREADS < n; i += 4 * EVAL_THREADS) {
+        const Fr c0 = ld(jb.poly + i), c1 = ld(jb.poly + i + EVAL_THREADS), c2 = ld(jb.poly + i + 2 * EVAL_THREADS),
+                 c3 = ld(jb.poly + i + 3 * EVAL_THREADS);
+        const Fr p0 = ld(w + i), p1 = ld(w + i + EVAL_THREADS), p2 = ld(w + i + 2 * EVAL_THREADS), p3 = ld(w + i + 3 * EVAL_THREADS);
+        acc = acc + c0 * p0;
+        acc = acc + c1 * p1;
+        acc = acc + c2 * p2;
+        acc = acc + c3 * p3;
+    }
+    for (; i < n; i += EVAL_THREADS) acc = acc + ld(jb.poly + i) * ld(w + i);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc = acc + shfl_down_fr(acc, off);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
@@ -948,13 +960,24 @@ struct LincombArgs {
     Fr coef[MAX_SET_POLYS];
     uint32_t count;
 };
-__global__ void lincomb_kernel(const LincombArgs* args, uint32_t n, Fr* out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// grid (n / 64, sets), 64 * parts threads: wave w of a workgroup sums the polynomials j = w, w + parts, ... of its 64
+// elements and wave 0 adds the partial sums up.  A set holds up to fifty polynomials: one thread per element is a chain
+// of fifty products, which is what a lone proof waits for (parts = 4); a pool lane keeps one wave per 64 elements.
+__global__ __launch_bounds__(256) void lincomb_kernel(const LincombArgs* args, uint32_t n, Fr* out) {
+    __shared__ Fr part_sum[3][64];
+    const uint32_t lane = threadIdx.x & 63, part = threadIdx.x >> 6, parts = blockDim.x >> 6;
+    const uint32_t i = blockIdx.x * 64 + lane;
     const LincombArgs& a = args[blockIdx.y];
-    if (i >= n) return;
     Fr acc = Fr::zero();
-    for (uint32_t j = 0; j < a.count; j++) acc = acc + a.coef[j] * ld(a.poly[j] + i);
-    st(out + (size_t)blockIdx.y * n + i, acc);
+    if (i < n)
+        for (uint32_t j = part; j < a.count; j += parts) acc = acc + a.coef[j] * ld(a.poly[j] + i);
+    if (parts > 1) {
+        if (part) part_sum[part - 1][lane] = acc;
+        __syncthreads();
+        if (part) return;
+        for (uint32_t p = 1; p < parts; p++) acc = acc + part_sum[p - 1][lane];
+    }
+    if (i < n) st(out + (size_t)blockIdx.y * n + i, acc);
 }
 
 // d[p][i] = omega^i - point_p
