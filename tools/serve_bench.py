@@ -4,26 +4,38 @@
    python tools/serve_bench.py [--clients 48] [--requests 20] [--lanes 16] [--client-procs 4]
 By default server and clients share one process (asyncio); with --client-procs the clients run in processes of their own
 and the server's interpreter only serves.  The clients verify nothing, they count and time."""
-import argparse, asyncio, importlib, json, os, random, statistics, struct, sys, time
+import argparse, asyncio, base64, importlib, json, os, random, statistics, struct, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+async def exchange(reader, writer, request, http):
+    """one request and its answer on an open connection: the enclave framing (4-byte length + JSON both ways) or, with
+    `http`, one keep-alive HTTP/1.1 request whose answer carries a Content-Length"""
+    writer.write(request)
+    await writer.drain()
+    if not http:
+        (size,) = struct.unpack(">I", await reader.readexactly(4))
+        body = await reader.readexactly(size)
+    else:
+        head = await reader.readuntil(b"\r\n\r\n")
+        assert head.startswith(b"HTTP/1.1 200"), head[:200]
+        size = next(int(l.split(b":")[1]) for l in head.split(b"\r\n") if l.lower().startswith(b"content-length"))
+        body = await reader.readexactly(size)
+    assert b"EncryptedProof" in body, body[:200]
+
+
 def client_process(conn, first, count, n_requests):
     """--client-procs: `count` connections in a process of their own (plain asyncio and sockets: no library, no GPU), so
-    that the server's interpreter serves requests only.  Protocol with the parent over `conn`: (port, frames) in, "ready"
-    out after the warm-up, "go" in, the request latencies out."""
-    port, frames = conn.recv()
+    that the server's interpreter serves requests only.  Protocol with the parent over `conn`: (port, requests, http) in,
+    "ready" out after the warm-up, "go" in, the request latencies out."""
+    port, frames, http = conn.recv()
 
     async def one(i, n, lat):
         reader, writer = await asyncio.open_connection("127.0.0.1", port)
         for j in range(n):
             t0 = time.perf_counter()
-            writer.write(frames[(i + j) % len(frames)])
-            await writer.drain()
-            (size,) = struct.unpack(">I", await reader.readexactly(4))
-            body = await reader.readexactly(size)
-            assert b"EncryptedProof" in body, body[:200]
+            await exchange(reader, writer, frames[(i + j) % len(frames)], http)
             lat.append(time.perf_counter() - t0)
         writer.close()
 
@@ -72,6 +84,7 @@ def main():
     shp.prefer_sleeping_waits(a.lanes)
     plan, lay = circuits.build_withdraw_plan()
     assert a.pools == 1 or a.native, "--pools needs --native"
+    assert not a.http or a.native, "--http needs --native"
     if a.pools > 1:
         os.environ.setdefault("SHP_MSM_TABLE_GB", str(200 // (2 * a.pools)))     # every pool's SRS builds its own tables on the one GPU
     ctxs, keys, pools = [], [], []
@@ -91,17 +104,19 @@ def main():
                   "token_address": le(wit[lay.TOKEN]), "path": [b for x in wit[4:4 + 7 * h] for b in le(x)], "value": le(wit[lay.VALUE]),
                   "nullifier_new": le(wit[lay.NULLIFIER_NEW]), "commitment": le(wit[lay.COMMITMENT]), "mac_salt": le(wit[lay.MAC_SALT])}
         payload = {"circuit_type": "Withdraw", "user_public_key": [], "circuit_inputs": list(json.dumps(inputs).encode())}
-        reqs.append(S.encode_frame({"GenerateProof": {"payload": list(json.dumps(payload).encode())}}))
+        if a.http:
+            body = json.dumps({"payload": base64.b64encode(json.dumps(payload).encode()).decode()}).encode()
+            reqs.append(b"POST /proof HTTP/1.1\r\nHost: bench\r\nContent-Type: application/json\r\nContent-Length: %d\r\n\r\n"
+                        % len(body) + body)
+        else:
+            reqs.append(S.encode_frame({"GenerateProof": {"payload": list(json.dumps(payload).encode())}}))
     lat = []
 
     async def client(i, port):
         reader, writer = await asyncio.open_connection("127.0.0.1", port)
         for j in range(a.requests):
             t0 = time.perf_counter()
-            writer.write(reqs[(i + j) % len(reqs)])
-            await writer.drain()
-            resp = await S.read_frame(reader)
-            assert "EncryptedProof" in resp, resp
+            await exchange(reader, writer, reqs[(i + j) % len(reqs)], a.http)
             lat.append(time.perf_counter() - t0)
         writer.close()
 
@@ -126,7 +141,7 @@ def main():
         async with srv:
             if procs:
                 for _, conn in procs:
-                    conn.send((port, reqs))
+                    conn.send((port, reqs, a.http))
                 for _, conn in procs:                                                  # every process has warmed up
                     assert await loop.run_in_executor(None, conn.recv) == "ready"
                 t0 = time.perf_counter()
@@ -144,7 +159,7 @@ def main():
     el = asyncio.run(run())
     lat.sort()
     n = len(lat)
-    print(json.dumps({"serve_path": "TCP + TEE JSON framing + shp_pool", "front": "native (shp_server)" if a.native else "serve.py (asyncio)", "clients": a.clients, "client_processes": a.client_procs,
+    print(json.dumps({"serve_path": ("HTTP POST /proof" if a.http else "TCP + TEE JSON framing") + " + shp_pool", "front": "native (shp_server)" if a.native else "serve.py (asyncio)", "clients": a.clients, "client_processes": a.client_procs,
                       "lanes": a.lanes, "pools": a.pools, "window_bits": [params.msm_info(b)[1] for b in (1, 0)],
                       "proofs_per_pool": [p_.stats()[0] for p_ in pools], "requests": n,
                       "request_bytes": len(reqs[0]), "proofs_per_s": n / el, "latency_ms_p50": 1e3 * lat[n // 2],

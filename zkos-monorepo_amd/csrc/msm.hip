@@ -1177,9 +1177,9 @@ void msm_launch_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace
     SHP_REQUIRE(busy_wgs < (1ull << 31), SHP_ERR_INVALID_ARG, "msm: launch too large");
     // T windows per lane: all of them when the launch fills the chip anyway (least tree overhead),
     // shorter chains for small launches (latency)
-    // (measured: a lone proof's p50 is 2.45 / 2.27 / 2.22 / 2.21 / 2.27 / 2.30 / 2.46 ms at 256 / 384 / 512 / 640 / 768 /
-    // 1024 / 2048 waves; 16 pool lanes peak at 512 too)
-    static const uint64_t base_waves = getenv("SHP_MSM_MIN_WAVES") ? (uint64_t)atol(getenv("SHP_MSM_MIN_WAVES")) : 512;
+    // (measured: a lone proof's p50 is 1.87 / 1.82 / 1.82 / 1.79 / 1.84 / 1.88 ms at 384 / 512 / 640 / 768 / 1024 / 1536
+    // waves -- a shallow optimum, 768 ahead in every later run as well; pool lanes set their own figure, 512)
+    static const uint64_t base_waves = getenv("SHP_MSM_MIN_WAVES") ? (uint64_t)atol(getenv("SHP_MSM_MIN_WAVES")) : 768;
     const uint64_t min_waves = ws.min_waves ? ws.min_waves : base_waves;
     // the fewest window groups that reach min_waves, the windows spread evenly over them
     const uint64_t per_group = busy_wgs * (MSM_THREADS / 64);
