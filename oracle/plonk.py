@@ -24,8 +24,8 @@ from . import binding as B
 
 R = B.R_MOD
 Q = B.Q_MOD
-OP_CONST, OP_ADV, OP_FIX, OP_INST, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_OUT = range(9)
-W_INPUT, W_CONST, W_COPY, W_ADD, W_SUB, W_MUL, W_ADDC, W_MULC, W_POW7, W_BITS, W_SHR = range(11)
+OP_CONST, OP_ADV, OP_FIX, OP_INST, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_OUT, OP_CHAL = range(10)
+W_INPUT, W_CONST, W_COPY, W_ADD, W_SUB, W_MUL, W_ADDC, W_MULC, W_POW7, W_BITS, W_SHR, W_CHAL = range(12)
 COL_ADVICE, COL_FIXED, COL_INSTANCE = 0, 1, 2
 
 
@@ -112,7 +112,7 @@ class Plan:
     def __init__(self, data: bytes):
         assert data[:4] == b"SHPL", "not a circuit plan"
         h = struct.unpack_from("<20I", data, 4)
-        assert h[0] == 1
+        assert h[0] in (1, 2)
         (_, self.k, self.num_advice, self.num_fixed, self.num_instance, self.bf, self.degree, naq, nfq, niq, npc,
          ncst, ngi, self.gate_slots, self.num_gates, nlk, self.n_winputs, nwo, self.n_wscratch, nim) = h
         self.n = 1 << self.k
@@ -159,6 +159,17 @@ class Plan:
         self.wops = [struct.unpack_from("<8I", data, off + 32 * i) for i in range(nwo)]
         off += 32 * nwo
         self.instance_map = pairs(nim, "<II")
+        # version 2: phases (halo2's advice_column_in / challenge_usable_after; codegen/util.rs:70-96)
+        self.num_phases, self.advice_phase, self.challenge_phase, self.wops_end = 1, [0] * self.num_advice, [], [nwo]
+        if h[0] == 2:
+            self.num_phases, nch = struct.unpack_from("<2I", data, off)
+            off += 8
+            self.advice_phase = list(struct.unpack_from("<%dI" % self.num_advice, data, off))
+            off += 4 * self.num_advice
+            self.challenge_phase = list(struct.unpack_from("<%dI" % nch, data, off))
+            off += 4 * nch
+            self.wops_end = list(struct.unpack_from("<%dI" % self.num_phases, data, off))
+            off += 4 * self.num_phases
         assert off == len(data), "trailing bytes in plan"
         self.usable = self.n - (self.bf + 1)
         self.ext_k = self.k
@@ -170,14 +181,23 @@ class Plan:
 
 
 # ------------------------------------------------------------------------------ witness VM
-def synthesize(plan: Plan, inputs):
-    """P1: run the plan's witness program over canonical ints -> advice[col][row], instances"""
+def new_grid(plan: Plan):
+    return [[0] * plan.n for _ in range(plan.num_advice)] + [[0] * max(plan.n_wscratch, 1)]
+
+
+def synthesize(plan: Plan, inputs, challenges=(), grid=None, phase=None):
+    """P1: run the plan's witness program over canonical ints -> advice[col][row], instances.
+    phase: run only that phase's part of the program, on `grid` (the state the earlier phases left), with the challenges
+    drawn so far; None = the whole program (a single-phase plan, or all challenges known up front)"""
     assert len(inputs) == plan.n_winputs
     A = plan.num_advice
-    grid = [[0] * plan.n for _ in range(A)] + [[0] * max(plan.n_wscratch, 1)]
+    grid = new_grid(plan) if grid is None else grid
     cst = plan.consts
-    for op, dc, dr, ac, ar, bc, br, imm in plan.wops:
+    lo = 0 if phase in (None, 0) else plan.wops_end[phase - 1]
+    hi = len(plan.wops) if phase is None else plan.wops_end[phase]
+    for op, dc, dr, ac, ar, bc, br, imm in plan.wops[lo:hi]:
         if op == W_INPUT: v = inputs[imm] % R
+        elif op == W_CHAL: v = challenges[imm]
         elif op == W_CONST: v = cst[imm]
         elif op == W_COPY: v = grid[ac][ar]
         elif op == W_ADD: v = (grid[ac][ar] + grid[bc][br]) % R
@@ -196,11 +216,12 @@ def synthesize(plan: Plan, inputs):
 
 
 # ------------------------------------------------------------------------------ programs
-def run_program_vec(prog, nslots, consts, adv, fix, inst, size):
+def run_program_vec(prog, nslots, consts, adv, fix, inst, size, chal=()):
     """vectorised interpreter: adv/fix/inst are callables query_index -> (size,4) array; yields OUT values"""
     slots = [None] * nslots
     for op, dst, a, b in prog:
         if op == OP_CONST: slots[dst] = vfill(size, fe(consts[a]))
+        elif op == OP_CHAL: slots[dst] = vfill(size, fe(chal[a]))
         elif op == OP_ADV: slots[dst] = adv(a)
         elif op == OP_FIX: slots[dst] = fix(a)
         elif op == OP_INST: slots[dst] = inst(a)
@@ -212,10 +233,11 @@ def run_program_vec(prog, nslots, consts, adv, fix, inst, size):
         else: raise ValueError(op)
 
 
-def run_program_scalar(prog, nslots, consts, adv, fix, inst):
+def run_program_scalar(prog, nslots, consts, adv, fix, inst, chal=()):
     slots = [0] * nslots
     for op, dst, a, b in prog:
         if op == OP_CONST: slots[dst] = consts[a]
+        elif op == OP_CHAL: slots[dst] = chal[a]
         elif op == OP_ADV: slots[dst] = adv(a)
         elif op == OP_FIX: slots[dst] = fix(a)
         elif op == OP_INST: slots[dst] = inst(a)
@@ -227,7 +249,7 @@ def run_program_scalar(prog, nslots, consts, adv, fix, inst):
         else: raise ValueError(op)
 
 
-def mock_check(plan: Plan, advice, instances):
+def mock_check(plan: Plan, advice, instances, challenges=()):
     """MockProver-style row check of gates on the usable rows (debug aid; python ints)"""
     n = plan.n
     fixed = [[c.get(r, 0) for r in range(n)] for c in plan.fixed]
@@ -238,7 +260,7 @@ def mock_check(plan: Plan, advice, instances):
             plan.gate_prog, plan.gate_slots, plan.consts,
             lambda q: advice[plan.adv_q[q][0]][(row + plan.adv_q[q][1]) % n],
             lambda q: fixed[plan.fix_q[q][0]][(row + plan.fix_q[q][1]) % n],
-            lambda q: inst[(row + plan.inst_q[q][1]) % n]))
+            lambda q: inst[(row + plan.inst_q[q][1]) % n], challenges))
         for gi, v in enumerate(outs):
             if v:
                 bad.append((row, gi))
@@ -447,7 +469,9 @@ def prove(pk: ProvingKey, srs, inputs, seed: bytes, return_trace=False, randomne
     ChaCha20 blinding stream; draws are consumed in the order include/shielder_hip.h gives at shp_prove_with_randomness.
     randomness: (count, 4) Montgomery array of pre-drawn Fr::random values used INSTEAD of the seed's stream (the
     reference's `rng` handed over as its draws); assigned: (advice_ints[col][row], instances) from the caller's own
-    synthesis instead of the plan's witness program."""
+    synthesis instead of the plan's witness program; for a plan with several phases a callable
+    assigned(phase, challenges) -> (advice_ints[col][row], instances) asked once per phase (the columns of that phase are
+    read from its answer)."""
     plan = pk.plan
     n, k, ek, bf, u = plan.n, plan.k, plan.ext_k, plan.bf, plan.usable
     A = plan.num_advice
@@ -465,21 +489,35 @@ def prove(pk: ProvingKey, srs, inputs, seed: bytes, return_trace=False, randomne
         return out
 
     trace = {}
-    # P0
-    advice_ints, instances = assigned if assigned is not None else synthesize(plan, inputs)
-    tr = Transcript(pk.vk_digest)
-    for v in instances:
-        tr.common_scalar(v)
-    # P1: blinding rows, then one (unused) blind per column
-    advice = []
-    for c in range(A):
-        col = B.fr_array(advice_ints[c])
-        col[u:] = draw(bf + 1)
-        advice.append(col)
-    draw(A)
-    # P2
-    for c in range(A):
-        tr.write_point(B.msm(srs.g_lagrange, advice[c]))
+    # P0-P2, once per phase (halo2 create_proof: synthesize with the challenges known so far, blind and commit the columns
+    # of this phase, then squeeze the challenges usable after it; proof layout Halo2Verifier.sol:267-282)
+    advice = [None] * A
+    chal = [None] * len(plan.challenge_phase)
+    grid = new_grid(plan)
+    tr = None
+    for ph in range(plan.num_phases):
+        if assigned is None:
+            advice_ints, inst_now = synthesize(plan, inputs, chal, grid, ph)
+        else:
+            advice_ints, inst_now = assigned(ph, list(chal)) if callable(assigned) else assigned
+        if ph == 0:
+            instances = list(inst_now)
+            tr = Transcript(pk.vk_digest)
+            for v in instances:
+                tr.common_scalar(v)
+        cols = [c for c in range(A) if plan.advice_phase[c] == ph]
+        # P1: blinding rows, then one (unused) blind per column
+        for c in cols:
+            col = B.fr_array(advice_ints[c])
+            col[u:] = draw(bf + 1)
+            advice[c] = col
+        draw(len(cols))
+        # P2
+        for c in cols:
+            tr.write_point(B.msm(srs.g_lagrange, advice[c]))
+        for i, cp in enumerate(plan.challenge_phase):
+            if cp == ph:
+                chal[i] = tr.squeeze()
     inst_col = _lagrange_column(n, {i: v for i, v in enumerate(instances)})
     fixed = pk.fixed_values
     L = len(plan.lookups)
@@ -503,7 +541,7 @@ def prove(pk: ProvingKey, srs, inputs, seed: bytes, return_trace=False, randomne
     for (m, pi, si, pt, st) in plan.lookups:
         def compress(prog, ns):
             acc = None
-            for e in run_program_vec(prog, ns, plan.consts, lag_adv, lag_fix, lag_inst, n):
+            for e in run_program_vec(prog, ns, plan.consts, lag_adv, lag_fix, lag_inst, n, chal):
                 acc = e if acc is None else vadd(vscale(acc, fe(theta)), e)
             return acc
         cin, ctab = compress(pi, si), compress(pt, st)
@@ -591,7 +629,7 @@ def prove(pk: ProvingKey, srs, inputs, seed: bytes, return_trace=False, randomne
 
     h = np.zeros((ne, 4), dtype=np.uint64)
     fold = lambda acc, e: vfold(acc, fy, e)
-    for e in run_program_vec(plan.gate_prog, plan.gate_slots, plan.consts, ext_adv, ext_fix, ext_inst, ne):
+    for e in run_program_vec(plan.gate_prog, plan.gate_slots, plan.consts, ext_adv, ext_fix, ext_inst, ne, chal):
         h = fold(h, e)
     one_e = vfill(ne, fe(1))
     if plan.num_sets:
@@ -615,7 +653,7 @@ def prove(pk: ProvingKey, srs, inputs, seed: bytes, return_trace=False, randomne
     for (m, pi, si, pt, st), d in zip(plan.lookups, lk):
         def compress_ext(prog, ns):
             acc = None
-            for e in run_program_vec(prog, ns, plan.consts, ext_adv, ext_fix, ext_inst, ne):
+            for e in run_program_vec(prog, ns, plan.consts, ext_adv, ext_fix, ext_inst, ne, chal):
                 acc = e if acc is None else vadd(vscale(acc, fe(theta)), e)
             return acc
         Ain, Stab = compress_ext(pi, si), compress_ext(pt, st)
@@ -727,7 +765,7 @@ def prove(pk: ProvingKey, srs, inputs, seed: bytes, return_trace=False, randomne
     if return_trace:
         trace.update(advice=advice, instances=instances, theta=theta, beta=beta, gamma=gamma, y=y, x=x,
                      zeta=zeta_c, nu=nu, mu=mu, evals=evals, pz=pz, lk=lk, hcoef=hcoef, draws=ctr[0],
-                     adv_poly=adv_poly)
+                     adv_poly=adv_poly, challenges=list(chal))
         return bytes(tr.proof), instances, trace
     return bytes(tr.proof), instances
 
@@ -771,7 +809,15 @@ def verify(pk: ProvingKey, proof: bytes, instances, tau=None, g2=None, s_g2=None
     for v in instances:
         tr.common_scalar(v)
     try:
-        adv_c = [rd_point(tr) for _ in range(plan.num_advice)]
+        adv_c = [None] * plan.num_advice
+        chal = [None] * len(plan.challenge_phase)
+        for ph in range(plan.num_phases):
+            for c in range(plan.num_advice):
+                if plan.advice_phase[c] == ph:
+                    adv_c[c] = rd_point(tr)
+            for i, cp in enumerate(plan.challenge_phase):
+                if cp == ph:
+                    chal[i] = tr.squeeze()
         theta = tr.squeeze()
         lk_c = [(rd_point(tr), rd_point(tr)) for _ in range(L)]
         beta = tr.squeeze()
@@ -825,7 +871,7 @@ def verify(pk: ProvingKey, proof: bytes, instances, tau=None, g2=None, s_g2=None
     fix = lambda q: evals[(("fix", plan.fix_q[q][0]), plan.fix_q[q][1])]
     inst = lambda q: inst_eval
     numer = 0
-    for e in run_program_scalar(plan.gate_prog, plan.gate_slots, plan.consts, adv, fix, inst):
+    for e in run_program_scalar(plan.gate_prog, plan.gate_slots, plan.consts, adv, fix, inst, chal):
         numer = (numer * y + e) % R
     def col_eval(t, i):
         return evals[(("adv", i), 0)] if t == COL_ADVICE else evals[(("fix", i), 0)] if t == COL_FIXED else inst_eval
@@ -847,7 +893,7 @@ def verify(pk: ProvingKey, proof: bytes, instances, tau=None, g2=None, s_g2=None
     for l, (m, pi, si, pt, st) in enumerate(plan.lookups):
         def comp(prog, ns):
             acc = None
-            for e in run_program_scalar(prog, ns, plan.consts, adv, fix, inst):
+            for e in run_program_scalar(prog, ns, plan.consts, adv, fix, inst, chal):
                 acc = e if acc is None else (acc * theta + e) % R
             return acc
         Ain, Stab = comp(pi, si), comp(pt, st)
@@ -861,6 +907,8 @@ def verify(pk: ProvingKey, proof: bytes, instances, tau=None, g2=None, s_g2=None
     h_eval = numer * pow((xn - 1) % R, -1, R) % R
     evals[(("h",), 0)] = h_eval
     if trace is not None:
+        if chal:
+            trace.update(USER_CHALLENGES=list(chal))
         trace.update(THETA_MPTR=theta, BETA_MPTR=beta, GAMMA_MPTR=gamma, Y_MPTR=y, X_MPTR=x, ZETA_MPTR=zeta_c, NU_MPTR=nu,
                      MU_MPTR=mu, X_N_MPTR=xn, X_N_MINUS_1_INV_MPTR=pow((xn - 1) % R, -1, R), L_LAST_MPTR=l_last,
                      L_BLIND_MPTR=l_blind, L_0_MPTR=l_0, INSTANCE_EVAL_MPTR=inst_eval, QUOTIENT_EVAL_MPTR=h_eval)

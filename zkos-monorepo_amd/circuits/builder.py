@@ -8,21 +8,29 @@ exactly those the reference's verifier generator reads off a halo2 ConstraintSys
 (/root/reference/crates/halo2-verifier/src/lib/codegen/util.rs:42-131): k, blinding factors,
 advice/fixed/instance queries, permutation columns, gate polynomials, lookups, degree.
 
-Plan layout (little endian, version 1; parsed by csrc/plan.hpp):
+Plan layout (little endian; parsed by csrc/plan.hpp):
   header (20 x u32) | advice queries | fixed queries | instance queries | permutation columns |
   constants (32 B canonical LE) | gate program | lookup programs | fixed column values (sparse) |
   permutation mapping (u32[n] per permutation column) | witness program | instance map
+Version 2 (circuits with several phases: advice columns assigned after a challenge has been drawn, halo2's
+`advice_column_in(phase)` / `challenge_usable_after(phase)`, which the reference's verifier generator supports --
+codegen/util.rs:70-96, 133-165, templates/Halo2Verifier.sol:267-282) appends
+  num_phases | num_challenges | phase of every advice column | phase of every challenge | end of every phase in the
+  witness program (u32 each)
+and adds the expression leaf OP_CHAL (a = challenge index) and the witness op W_CHAL (imm = challenge index).  A circuit
+with one phase and no challenge is written as version 1, byte for byte as before.
 """
 import struct
 
 R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 MAGIC = b"SHPL"
 VERSION = 1
+VERSION_PHASES = 2
 
 # gate / lookup program opcodes
-OP_CONST, OP_ADV, OP_FIX, OP_INST, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_OUT = range(9)
+OP_CONST, OP_ADV, OP_FIX, OP_INST, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_OUT, OP_CHAL = range(10)
 # witness program opcodes
-W_INPUT, W_CONST, W_COPY, W_ADD, W_SUB, W_MUL, W_ADDC, W_MULC, W_POW7, W_BITS, W_SHR = range(11)
+W_INPUT, W_CONST, W_COPY, W_ADD, W_SUB, W_MUL, W_ADDC, W_MULC, W_POW7, W_BITS, W_SHR, W_CHAL = range(12)
 COL_ADVICE, COL_FIXED, COL_INSTANCE = 0, 1, 2
 
 
@@ -69,6 +77,7 @@ def Const(v): return Expr("const", (int(v) % R_MOD,), 0)
 def Adv(col, rot=0): return Expr("adv", (col, rot), 1)
 def Fix(col, rot=0): return Expr("fix", (col, rot), 1)
 def Inst(col, rot=0): return Expr("inst", (col, rot), 1)
+def Chal(index): return Expr("chal", (index,), 0)          # a challenge is a constant of the proof: degree 0
 
 
 class _Compiler:
@@ -80,7 +89,7 @@ class _Compiler:
     def compile(self, outputs):
         order, ids = [], {}
 
-        LEAVES = ("const", "adv", "fix", "inst")
+        LEAVES = ("const", "adv", "fix", "inst", "chal")
 
         def visit(e):
             # Leaves are re-materialised at every use instead of being kept alive across gates: a load
@@ -142,6 +151,7 @@ class _Compiler:
                 elif e.kind == "adv": prog.append((OP_ADV, dst, self.plan.adv_query(*e.args), 0))
                 elif e.kind == "fix": prog.append((OP_FIX, dst, self.plan.fix_query(*e.args), 0))
                 elif e.kind == "inst": prog.append((OP_INST, dst, self.plan.inst_query(*e.args), 0))
+                elif e.kind == "chal": prog.append((OP_CHAL, dst, e.args[0], 0))
                 elif e.kind == "add": prog.append((OP_ADD, dst, ksl[0], ksl[1]))
                 elif e.kind == "sub": prog.append((OP_SUB, dst, ksl[0], ksl[1]))
                 elif e.kind == "mul": prog.append((OP_MUL, dst, ksl[0], ksl[1]))
@@ -169,11 +179,42 @@ class PlanBuilder:
         self.n_winputs = 0
         self.n_wscratch = 0
         self.instance_map = []                     # (advice col, row) whose value is public input i
+        self.advice_phase = []                     # phase of every advice column
+        self.challenge_phase = []                  # challenge i is drawn after the commitments of this phase
+        self.wops_end = []                         # witness ops of phase p: [wops_end[p-1], wops_end[p])
 
     # ---- columns & queries
-    def advice_column(self):
+    def advice_column(self, phase=0):
         self.num_advice += 1
+        self.advice_phase.append(phase)
         return self.num_advice - 1
+
+    def challenge(self, phase=0):
+        """halo2's challenge_usable_after(phase): drawn from the transcript after the advice commitments of `phase`,
+        known to the witness program from phase + 1 on and to every expression"""
+        self.challenge_phase.append(phase)
+        return len(self.challenge_phase) - 1
+
+    def next_phase(self):
+        """the witness ops recorded from here on run after the challenges of the phase that ends here are known"""
+        self.wops_end.append(len(self.wops))
+
+    def num_phases(self):
+        return max(self.advice_phase + [0]) + 1
+
+    def _phase_tail(self):
+        """what version 2 appends (empty for a single-phase circuit without challenges)"""
+        P = self.num_phases()
+        if P == 1 and not self.challenge_phase:
+            return None
+        assert sorted(set(self.advice_phase)) == list(range(P)), "every phase needs an advice column"
+        assert all(ph < P for ph in self.challenge_phase), "challenge after a phase that does not exist"
+        assert all(any(ph == p for ph in self.challenge_phase) for p in range(P - 1)), "a phase before the last draws no challenge"
+        ends = list(self.wops_end) + [len(self.wops)] * (P - len(self.wops_end))
+        assert len(ends) == P and ends == sorted(ends) and ends[-1] == len(self.wops), "next_phase() calls do not match the phases"
+        assert all(self.advice_phase[c] == 0 for c, _ in self.instance_map), "public inputs are first-phase cells"
+        return struct.pack("<2I", P, len(self.challenge_phase)) + struct.pack("<%dI" % self.num_advice, *self.advice_phase) + \
+            struct.pack("<%dI" % len(self.challenge_phase), *self.challenge_phase) + struct.pack("<%dI" % P, *ends)
 
     def fixed_column(self):
         self.num_fixed += 1
@@ -241,7 +282,7 @@ class PlanBuilder:
         fixed values, copy constraints, witness program -- no compiled programs, no degree, no mapping."""
         self.build()                                   # registers every query and constant (idempotent)
         nodes, ids = [], {}
-        KIND = {"const": 0, "adv": 1, "fix": 2, "inst": 3, "add": 4, "sub": 5, "mul": 6, "neg": 7}
+        KIND = {"const": 0, "adv": 1, "fix": 2, "inst": 3, "add": 4, "sub": 5, "mul": 6, "neg": 7, "chal": 8}
 
         def node(e):
             k = id(e)
@@ -261,6 +302,7 @@ class PlanBuilder:
                 elif cur.kind == "adv": rec = (1, self.adv_query(*cur.args), 0)
                 elif cur.kind == "fix": rec = (2, self.fix_query(*cur.args), 0)
                 elif cur.kind == "inst": rec = (3, self.inst_query(*cur.args), 0)
+                elif cur.kind == "chal": rec = (8, cur.args[0], 0)
                 elif cur.kind == "neg": rec = (7, ids[id(kids[0])], 0)
                 else: rec = (KIND[cur.kind], ids[id(kids[0])], ids[id(kids[1])])
                 ids[id(cur)] = len(nodes)
@@ -275,8 +317,9 @@ class PlanBuilder:
         for op, dc, dr, ac, ar, bc, br, imm in self.wops:
             d, a, b_ = cell((dc, dr)), cell((ac, ar)), cell((bc, br))
             wops.append((op, d[0], d[1], a[0], a[1], b_[0], b_[1], imm))
-        hdr = [1, self.k, self.num_advice, self.num_fixed, self.num_instance, len(self.adv_q), len(self.fix_q), len(self.inst_q),
-               len(self.perm_cols), len(self.consts), len(nodes), len(gates), len(lookups), len(self.copies), 0,
+        tail = self._phase_tail()
+        hdr = [1 if tail is None else 2, self.k, self.num_advice, self.num_fixed, self.num_instance, len(self.adv_q), len(self.fix_q),
+               len(self.inst_q), len(self.perm_cols), len(self.consts), len(nodes), len(gates), len(lookups), len(self.copies), 0,
                self.n_winputs, len(wops), self.n_wscratch, len(self.instance_map), 0]
         out = bytearray(b"SHCD" + struct.pack("<20I", *hdr))
         for lst in (self.adv_q, self.fix_q, self.inst_q):
@@ -308,7 +351,7 @@ class PlanBuilder:
             out += struct.pack("<8I", *ins)
         for c, r in self.instance_map:
             out += struct.pack("<II", c, r)
-        return bytes(out)
+        return bytes(out) + (tail or b"")
 
     # ---- serialisation
     def build(self):
@@ -361,7 +404,8 @@ class PlanBuilder:
         for op, dc, dr, ac, ar, bc, br, imm in self.wops:
             d, a, b = cell((dc, dr)), cell((ac, ar)), cell((bc, br))
             wops.append((op, d[0], d[1], a[0], a[1], b[0], b[1], imm))
-        hdr = [VERSION, self.k, self.num_advice, self.num_fixed, self.num_instance, bf, deg,
+        tail = self._phase_tail()
+        hdr = [VERSION if tail is None else VERSION_PHASES, self.k, self.num_advice, self.num_fixed, self.num_instance, bf, deg,
                len(self.adv_q), len(self.fix_q), len(self.inst_q), len(self.perm_cols), len(self.consts),
                len(gate_prog), gate_slots, len(self.gates), len(lk),
                self.n_winputs, len(wops), self.n_wscratch, len(self.instance_map)]
@@ -395,4 +439,4 @@ class PlanBuilder:
             out += struct.pack("<8I", *ins)
         for c, r in self.instance_map:
             out += struct.pack("<II", c, r)
-        return bytes(out)
+        return bytes(out) + (tail or b"")
