@@ -37,7 +37,7 @@ TEMPLATE = "/root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol"
 W = 1 << 256
 Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-OP_CONST, OP_ADV, OP_FIX, OP_INST, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_OUT = range(9)
+OP_CONST, OP_ADV, OP_FIX, OP_INST, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_OUT, OP_CHAL = range(10)
 COL_ADVICE, COL_FIXED, COL_INSTANCE = 0, 1, 2
 
 
@@ -127,7 +127,7 @@ def group_backward_adjacent(items, ptr_of, step):
 
 # =============================================================================== codegen/util.rs: Meta, Data
 class Meta:
-    """ConstraintSystemMeta::new (util.rs:42-131) for a single-phase circuit given as a plan"""
+    """ConstraintSystemMeta::new (util.rs:42-131) for a circuit given as a plan"""
 
     def __init__(self, plan):
         self.num_fixeds = plan.num_fixed
@@ -141,10 +141,22 @@ class Meta:
         self.fixed_queries = [tuple(q) for q in plan.fix_q]
         self.num_evals = (len(self.advice_queries) + len(self.fixed_queries) + 1 + len(self.permutation_columns)
                           + (3 * self.num_permutation_zs - 1) + 5 * len(plan.lookups))
-        self.num_user_advices = [plan.num_advice]
-        self.num_user_challenges = [0]
-        self.advice_indices = list(range(plan.num_advice))
-        self.challenge_indices = []
+        num_phase = max(plan.advice_phase + [0]) + 1
+
+        def remapping(phase):
+            """util.rs:73-94: how many of each phase, and every item's position once they are ordered by phase"""
+            nums = [0] * num_phase
+            for ph in phase:
+                nums[ph] += 1
+            state = [sum(nums[:i]) for i in range(num_phase)]
+            index = []
+            for ph in phase:
+                index.append(state[ph])
+                state[ph] += 1
+            return nums, index
+
+        self.num_user_advices, self.advice_indices = remapping(plan.advice_phase)
+        self.num_user_challenges, self.challenge_indices = remapping(plan.challenge_phase)
         self.rotation_last = -(plan.bf + 1)
         rots = [q[1] for q in self.advice_queries] + [q[1] for q in self.fixed_queries]
         if self.num_permutation_zs > 0: rots += [0, 1]
@@ -238,6 +250,7 @@ class Evaluator:
             elif op == OP_ADV: val = self.eval(COL_ADVICE, *P.adv_q[a])
             elif op == OP_FIX: val = self.eval(COL_FIXED, *P.fix_q[a])
             elif op == OP_INST: val = str(self.data.instance_eval)
+            elif op == OP_CHAL: val = str(self.data.challenges[a])              # evaluator.rs:264-269
             elif op == OP_ADD: val = "addmod(%s, %s, r)" % (slot[a], slot[b])
             elif op == OP_SUB: val = "addmod(%s, sub(r, %s), r)" % (slot[a], slot[b])
             elif op == OP_MUL: val = "mulmod(%s, %s, r)" % (slot[a], slot[b])
@@ -937,6 +950,9 @@ class Contract:
             pass
         assert y.ret is not None and len(y.ret) == 32
         words = {n_: "0x%064x" % y.mload(self.consts[n_]) for n_ in TRACE_WORDS}
+        if self.meta.challenge_indices:                    # the user challenges, in the circuit's own numbering
+            base = self.consts["CHALLENGE_MPTR"]
+            words["USER_CHALLENGES"] = ["0x%064x" % y.mload(base + 32 * i) for i in self.meta.challenge_indices]
         if y.mload(self.consts["X_N_MPTR"]) == 0:          # returned before the Lagrange stage: invalid length, point or scalar
             words = None
         return int.from_bytes(y.ret, "big") == 1, words
@@ -956,7 +972,9 @@ def main():
             ("withdraw-shaped plan, k = 9, synthetic SRS (g2 = the ceremony file's generator, s_g2 = tau g2)", "build_withdraw_plan",
              dict(k=9, height=1, range_bits=4, range_chunks=8), "synthetic"),
             ("deposit-shaped plan, k = 11, the reference's own resources/ppot_0080_11_raw", "build_deposit_plan",
-             dict(k=11, height=3, range_bits=8, range_chunks=10), "real")):
+             dict(k=11, height=3, range_bits=8, range_chunks=10), "real"),
+            ("three-phase plan (advice columns after challenges, util.rs:70-96), k = 6, synthetic SRS", "build_phased_plan",
+             dict(k=6, rows=20), "synthetic")):
         plan_bytes, lay = getattr(C, builder)(**kw)
         plan = PL.Plan(plan_bytes)
         if srs_kind == "real":
@@ -970,7 +988,10 @@ def main():
         opk = PL.keygen(plan, srs)
         g1 = tuple(O.g1_affine_ints(srs.g[:1])[0])
         contract = Contract(O, PA, plan, opk, g1, g2b, sg2b)
-        wit = C.withdraw_witness_inputs(lay, H, random.Random(2025), 2**31 + 5, 2**20 + 3)
+        if builder == "build_phased_plan":
+            wit = C.phased_witness_inputs(lay, random.Random(2025))
+        else:
+            wit = C.withdraw_witness_inputs(lay, H, random.Random(2025), 2**31 + 5, 2**20 + 3)
         seed = bytes(range(1, 33))
         proof, inst = PL.prove(opk, srs, wit, seed)
         rnd = random.Random(7)
@@ -978,8 +999,9 @@ def main():
         for pos in (5, 64 * plan.num_advice + 3, len(proof) - 130, len(proof) - 100, len(proof) - 1):
             bad = bytearray(proof); bad[pos] ^= 1 << rnd.randrange(8)
             variants.append(("byte %d flipped" % pos, bytes(bad), inst))
-        wrong = list(inst); wrong[1] = (wrong[1] + 1) % R
-        variants.append(("public input 1 off by one", proof, wrong))
+        wi = min(1, len(inst) - 1)
+        wrong = list(inst); wrong[wi] = (wrong[wi] + 1) % R
+        variants.append(("public input %d off by one" % wi, proof, wrong))
         variants.append(("one byte short", proof[:-1], inst))
         vectors = []
         for label, pr_, ins_ in variants:

@@ -31,6 +31,12 @@ def rebuild(oracle, case):
     return PL, C, plan_bytes, plan, lay, srs
 
 
+def witness_of(C, case, lay, hash_fn):
+    if case["builder"] == "build_phased_plan":
+        return C.phased_witness_inputs(lay, random.Random(case["witness_seed"]))
+    return C.withdraw_witness_inputs(lay, hash_fn, random.Random(case["witness_seed"]), case["balance"], case["value"])
+
+
 @pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: c["builder"] + "_k%d" % c["kwargs"]["k"])
 def test_oracle_verifier_reproduces_the_contract(oracle, case):
     PL, C, plan_bytes, plan, lay, srs = rebuild(oracle, case)
@@ -39,7 +45,7 @@ def test_oracle_verifier_reproduces_the_contract(oracle, case):
     g2, s_g2 = bytes.fromhex(case["g2"]), bytes.fromhex(case["s_g2"])
     # the proof the contract accepted is the proof the oracle produces today
     H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
-    wit = C.withdraw_witness_inputs(lay, H, random.Random(case["witness_seed"]), case["balance"], case["value"])
+    wit = witness_of(C, case, lay, H)
     proof, inst = PL.prove(opk, srs, wit, bytes.fromhex(case["blinding_seed"]))
     assert proof.hex() == case["vectors"][0]["proof"] and ["0x%064x" % v for v in inst] == case["vectors"][0]["instances"]
     for vec in case["vectors"]:
@@ -49,6 +55,8 @@ def test_oracle_verifier_reproduces_the_contract(oracle, case):
         if vec["trace"] is not None:
             for name in WORDS:
                 assert "0x%064x" % tr[name] == vec["trace"][name], f'{vec["label"]}: {name}'
+            # a circuit with several phases: the challenges the contract squeezed between the advice commitments
+            assert ["0x%064x" % v for v in tr.get("USER_CHALLENGES", [])] == vec["trace"].get("USER_CHALLENGES", []), vec["label"]
     assert case["vectors"][0]["accepted"] and not any(v["accepted"] for v in case["vectors"][1:])
     assert sum(v["trace"] is not None for v in case["vectors"]) >= 3        # full runs that end in a failed pairing are covered
 
@@ -65,7 +73,7 @@ def test_native_verifier_reproduces_the_contract(shp, oracle, gpu_ctx, case):
     assert params.g2() == (bytes.fromhex(case["g2"]), bytes.fromhex(case["s_g2"]))
     pk = shp.ProvingKey(gpu_ctx, params, plan_bytes)
     assert pk.vk_digest().hex() == case["vk_digest"]
-    wit = C.withdraw_witness_inputs(lay, shp.poseidon2_hash_host, random.Random(case["witness_seed"]), case["balance"], case["value"])
+    wit = witness_of(C, case, lay, shp.poseidon2_hash_host)
     pr = shp.Prover(pk)
     proof, inst = pr.prove(wit, bytes.fromhex(case["blinding_seed"]))
     assert proof.hex() == case["vectors"][0]["proof"], "the HIP prover's proof is not the one the reference's contract accepted"
