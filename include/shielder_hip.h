@@ -294,10 +294,34 @@ int32_t shp_prove_with_randomness(shp_prover* p, const uint8_t* witness_le32, si
  *   assigned_rows  rows [assigned_rows, usable) of every column are zero and are not read (0 = all usable rows)
  *   instances      the public inputs (Montgomery limbs), n_instances = the plan's
  *   randomness     pre-drawn Fr (see above), or NULL to expand `seed`
- * The plan's witness program is not run.  Same proof bytes as shp_prove when the columns are the witness program's. */
+ * The plan's witness program is not run.  Same proof bytes as shp_prove when the columns are the witness program's.
+ * A circuit with several phases cannot hand over all columns at once: shp_prove_assigned_phased below. */
 int32_t shp_prove_assigned(shp_prover* p, const uint64_t* advice, size_t n_columns, size_t n_rows, size_t assigned_rows,
                            const uint64_t* instances, size_t n_instances, const uint64_t* randomness, size_t n_draws,
                            const uint8_t* seed, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+/* generate_proof for a circuit with SEVERAL PHASES -- advice columns assigned after challenges have been squeezed from the
+ * transcript (halo2's advice_column_in(SecondPhase) / challenge_usable_after(FirstPhase)).  None of the reference's circuits
+ * has a second phase, but its verifier generator supports them
+ * (/root/reference/crates/halo2-verifier/src/lib/codegen/util.rs:70-96, 133-165, templates/Halo2Verifier.sol:267-282), and
+ * halo2's create_proof calls the circuit's `synthesize` once per phase with the challenges known so far.  `synthesize` is
+ * that call: the library invokes it once per phase, in order, on the calling thread, with
+ *   phase          0, 1, ...
+ *   challenges     n_challenges field elements (Montgomery limbs, 4 x u64 each), the circuit's challenges by index; those
+ *                  of phases that have not been committed yet are zero
+ * and reads from the returned block (n_columns x n_rows, column-major, Montgomery limbs, as shp_prove_assigned) the columns
+ * of that phase; NULL aborts the proof (SHP_ERR_INVALID_ARG).  The block need only stay valid until the next call.
+ * Randomness draw order for such a circuit: per phase, the blinding rows of the phase's columns and their unused blinds;
+ * then as at shp_prove_with_randomness.  shp_pk_phases reports the phase of every advice column. */
+typedef const uint64_t* (*shp_phase_fn)(void* user, uint32_t phase, const uint64_t* challenges, size_t n_challenges);
+int32_t shp_prove_assigned_phased(shp_prover* p, shp_phase_fn synthesize, void* user, size_t n_columns, size_t n_rows,
+                                  size_t assigned_rows, const uint64_t* instances, size_t n_instances,
+                                  const uint64_t* randomness, size_t n_draws, const uint8_t* seed, uint8_t* proof_out,
+                                  size_t proof_cap, size_t* proof_len);
+/* Phases of the key's circuit: how many, how many challenges, how many advice columns, and (optional, advice_cap >=
+ * number of advice columns) the phase of every advice column.  The proof carries the advice commitments phase by phase,
+ * by column within a phase. */
+int32_t shp_pk_phases(const shp_pk* pk, uint32_t* num_phases, uint32_t* num_challenges, uint32_t* num_advice,
+                      uint32_t* advice_phase, size_t advice_cap);
 /* Host threads the lane uses for the witness program (the reference's `synthesize`, rayon in its
  * multithreading feature): the program is cut into independent tasks once per lane (Poseidon2
  * permutations of the Merkle levels run side by side).  Default 8 (env SHP_WITNESS_THREADS); a
@@ -325,7 +349,8 @@ int32_t shp_verify(const shp_pk* pk, const uint8_t* proof, size_t proof_len, con
  * (/root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:39-73), as 22 big-endian 32-byte words in this order:
  * theta, beta, gamma, y, x, zeta, nu, mu, x^n, (x^n - 1)^-1, l_last, l_blind, l_0, instance_eval, quotient_eval,
  * quotient commitment x, y, g1 scalar (= -r_eval), pairing lhs x, y, pairing rhs x, y.  Words the run did not reach
- * (a malformed proof is refused early) stay zero.  For cross-checks against the contract's own run. */
+ * (a malformed proof is refused early) stay zero.  For a circuit with several phases and words_cap >= (22 + its number
+ * of challenges) * 32 the circuit's challenges follow as words 22, 23, ...  For cross-checks against the contract's own run. */
 int32_t shp_verify_trace(const shp_pk* pk, const uint8_t* proof, size_t proof_len, const uint8_t* instances_le32,
                          size_t n_instances, int32_t* accepted, uint8_t* words_be32, size_t words_cap);
 /* HIP-event timing of the lane's kernel launches, on the stream they run on: enable (resets the

@@ -1,0 +1,166 @@
+"""GPU: circuits with several phases through the HIP prover -- proof bytes equal the oracle's, the native verifier accepts
+them and squeezes the same challenges, the caller's own synthesis runs phase by phase through the callback, pools, saved
+keys and plans compiled by the library behave the same.  The three-phase proof is the one the reference's contract text
+accepted (tests/test_verifier_trace.py covers that case too)."""
+import importlib
+import random
+
+import numpy as np
+import pytest
+
+from phased_plans import random_phased_plan
+
+pytestmark = pytest.mark.gpu
+TAU = 0x1234567890ABCDEF1234567890ABCDEF55
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def setup(shp, oracle, gpu_ctx, plan_bytes):
+    from oracle import plonk as PL
+    plan = PL.Plan(plan_bytes)
+    osrs = oracle.srs_synthetic(plan.k, TAU)
+    opk = PL.keygen(plan, osrs)
+    params = shp.Params.synthetic(gpu_ctx, plan.k, TAU)
+    pk = shp.ProvingKey(gpu_ctx, params, plan_bytes)
+    return PL, plan, osrs, opk, params, pk
+
+
+def test_three_phase_plan_proof_bytes_and_verifier(shp, oracle, gpu_ctx):
+    C = importlib.import_module("zkos-monorepo_amd.circuits")
+    plan_bytes, rows = C.build_phased_plan()
+    PL, plan, osrs, opk, params, pk = setup(shp, oracle, gpu_ctx, plan_bytes)
+    assert pk.vk_digest() == opk.vk_digest
+    assert pk.phases() == (3, 4, [0, 1, 0, 2, 1]) and pk.compiled_level() == 0
+    pr = shp.Prover(pk)
+    for s in (1, 2):
+        wit = C.phased_witness_inputs(rows, random.Random(s))
+        seed = bytes([s]) * 32
+        want_proof, want_inst, tr = PL.prove(opk, osrs, wit, seed, return_trace=True)
+        got = pr.prove(wit, seed)
+        assert got[1] == want_inst and got[0] == want_proof
+        pr.mode(True)                                       # a pool lane's scheduling: same bytes
+        assert pr.prove(wit, seed) == (want_proof, want_inst)
+        pr.mode(False)
+        assert pk.public_inputs(wit) == want_inst          # first-phase cells: no proof, no challenge needed
+        ok, words, chal = pk.verify_trace(want_proof, want_inst, with_challenges=True)
+        assert ok and chal == tr["challenges"] and words[0] == tr["theta"]
+        assert pk.verify(want_proof, want_inst)
+        bad = bytearray(want_proof); bad[64 * 3 + 7] ^= 1    # a second-phase commitment
+        assert not pk.verify(bytes(bad), want_inst)
+        assert not pk.verify(want_proof, [(want_inst[0] + 1) % R])
+    # pre-drawn randomness in the documented order (per phase: blinding rows of its columns, then their blinds)
+    draws = PL.draws(bytes([9]) * 32, 0, pk.n_draws)
+    wit = C.phased_witness_inputs(rows, random.Random(5))
+    assert pr.prove_with_randomness(wit, draws)[0] == PL.prove(opk, osrs, wit, None, randomness=draws)[0] == pr.prove(wit, bytes([9]) * 32)[0]
+    pr.close(); pk.close(); params.close()
+
+
+def test_phased_columns_from_the_callers_own_synthesis(shp, oracle, gpu_ctx):
+    """shp_prove_assigned_phased: the library asks for the columns phase by phase, handing over the challenges it squeezed;
+    here the caller's synthesis is the oracle's witness VM -- the bytes are those of the witness-program path"""
+    C = importlib.import_module("zkos-monorepo_amd.circuits")
+    plan_bytes, rows = C.build_phased_plan()
+    PL, plan, osrs, opk, params, pk = setup(shp, oracle, gpu_ctx, plan_bytes)
+    pr = shp.Prover(pk)
+    wit = C.phased_witness_inputs(rows, random.Random(11))
+    seed = bytes([11]) * 32
+    want_proof, want_inst, tr = PL.prove(opk, osrs, wit, seed, return_trace=True)
+    grid, seen = PL.new_grid(plan), []
+
+    def synthesize(phase, challenges):
+        seen.append((phase, list(challenges)))
+        adv, _ = PL.synthesize(plan, wit, challenges, grid, phase)
+        return np.stack([oracle.fr_array(col) for col in adv])
+    inst = oracle.fr_array(want_inst)
+    assert pr.prove_assigned_phased(synthesize, inst, seed=seed) == want_proof
+    ch = tr["challenges"]
+    assert seen == [(0, [0, 0, 0, 0]), (1, [ch[0], ch[1], 0, 0]), (2, [ch[0], ch[1], ch[2], 0])]
+    # only the rows the circuit assigns
+    grid = PL.new_grid(plan)
+    assert pr.prove_assigned_phased(synthesize, inst, assigned_rows=rows + 1, seed=seed) == want_proof
+    # the one-shot entry point cannot serve several phases; a callback that gives up or raises ends the proof cleanly
+    full = np.stack([oracle.fr_array(PL.ints(c)) for c in tr["advice"]])
+    with pytest.raises(shp.ShpError) as e:
+        pr.prove_assigned(full, inst, seed=seed)
+    assert e.value.code == shp.SHP_ERR_INVALID_ARG
+
+    def gives_up(phase, challenges):
+        if phase == 1:
+            raise KeyError("no witness for phase 1")
+        return synthesize(phase, challenges)
+    grid = PL.new_grid(plan)
+    with pytest.raises(KeyError):
+        pr.prove_assigned_phased(gives_up, inst, seed=seed)
+    grid = PL.new_grid(plan)
+    assert pr.prove(wit, seed)[0] == want_proof            # the lane is fine afterwards
+    # a single-phase key through the same entry point: asked once
+    v1, lay = C.build_withdraw_plan(k=9, height=1, range_bits=4, range_chunks=8)
+    plan1 = PL.Plan(v1)
+    osrs1 = oracle.srs_synthetic(9, TAU)
+    opk1 = PL.keygen(plan1, osrs1)
+    params1 = shp.Params.synthetic(gpu_ctx, 9, TAU)
+    pk1 = shp.ProvingKey(gpu_ctx, params1, v1)
+    pr1 = shp.Prover(pk1)
+    H = lambda xs: oracle.fr_ints(oracle.poseidon2_hash(oracle.fr_array(xs)))[0]
+    wit1 = C.withdraw_witness_inputs(lay, H, random.Random(2), 2**31 + 1, 2**20 + 2)
+    adv1, inst1 = PL.synthesize(plan1, wit1)
+    calls = []
+    once = lambda phase, challenges: (calls.append((phase, challenges)), np.stack([oracle.fr_array(c) for c in adv1]))[1]
+    assert pr1.prove_assigned_phased(once, oracle.fr_array(inst1), seed=seed) == PL.prove(opk1, osrs1, wit1, seed)[0]
+    assert calls == [(0, [])]
+    pr1.close(); pk1.close(); params1.close()
+    pr.close(); pk.close(); params.close()
+
+
+def test_phased_key_in_a_pool_saved_and_compiled_by_the_library(shp, oracle, gpu_ctx):
+    C = importlib.import_module("zkos-monorepo_amd.circuits")
+    plan_bytes, rows = C.build_phased_plan()
+    PL, plan, osrs, opk, params, pk = setup(shp, oracle, gpu_ctx, plan_bytes)
+    wits = [C.phased_witness_inputs(rows, random.Random(20 + i)) for i in range(12)]
+    seeds = [bytes([20 + i]) * 32 for i in range(12)]
+    want = [PL.prove(opk, osrs, w, s) for w, s in zip(wits, seeds)]
+    pool = shp.Pool(pk, 3)
+    tickets = [pool.submit(b"".join(int(x).to_bytes(32, "little") for x in w), s) for w, s in zip(wits, seeds)]
+    for t, (proof, inst) in zip(tickets, want):
+        assert pool.wait(t) == (proof, inst)
+    pool.close()
+    # a saved key comes back with its phases
+    pk2 = shp.ProvingKey.load(gpu_ctx, params, pk.save())
+    assert pk2.phases() == pk.phases()
+    pr2 = shp.Prover(pk2)
+    assert pr2.prove(wits[0], seeds[0]) == want[0]
+    pr2.close(); pk2.close()
+    # the plan the library compiles from the circuit description: another slot allocation, the same proofs as the oracle's
+    # over that plan
+    compiled = shp.plan_compile(C.build_phased_plan(describe=True)[0])
+    PLc, planc, _, opkc, paramsc, pkc = setup(shp, oracle, gpu_ctx, compiled)
+    prc = shp.Prover(pkc)
+    assert prc.prove(wits[1], seeds[1]) == PL.prove(opkc, osrs, wits[1], seeds[1])
+    # generate_keys_with_min_k over a larger SRS re-lays the plan out and keeps the phases
+    big = shp.Params.synthetic(gpu_ctx, 8, TAU)
+    small, kmin, pkm = shp.ProvingKey.generate_keys_with_min_k(gpu_ctx, big, shp.plan_retarget(plan_bytes, 8))
+    assert kmin == 6 and pkm.phases() == pk.phases() and pkm.vk_digest() == opk.vk_digest
+    prm = shp.Prover(pkm)
+    assert prm.prove(wits[2], seeds[2]) == want[2]
+    prm.close(); pkm.close(); small.close(); big.close()
+    prc.close(); pkc.close(); paramsc.close()
+    pk.close(); params.close()
+
+
+@pytest.mark.parametrize("seed", list(range(1, 1 + int(__import__("os").environ.get("FUZZ_PHASED_SEEDS", "24")))))
+def test_random_phased_plan_proof_bytes(shp, oracle, gpu_ctx, seed):
+    plan_bytes, k, values = random_phased_plan(seed)
+    PL, plan, osrs, opk, params, pk = setup(shp, oracle, gpu_ctx, plan_bytes)
+    pr = shp.Prover(pk)
+    sb = bytes([seed % 251 + 1]) * 32
+    want = PL.prove(opk, osrs, values, sb)
+    assert PL.verify(opk, want[0], want[1], tau=TAU)
+    got = pr.prove(values, sb)
+    assert got[1] == want[1], "public inputs differ"
+    assert got[0] == want[0], f"proof bytes differ (k={k}, phases={plan.advice_phase}, challenges={plan.challenge_phase})"
+    pr.mode(seed % 2 == 0)
+    assert pr.prove(values, sb) == want
+    assert pk.verify(*got)
+    bad = bytearray(got[0]); bad[(seed * 53) % len(bad)] ^= 1
+    assert not pk.verify(bytes(bad), got[1])
+    pr.close(); pk.close(); params.close()

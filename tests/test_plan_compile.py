@@ -19,7 +19,8 @@ def stock():
     C = importlib.import_module("zkos-monorepo_amd.circuits")
     small = dict(k=9, height=1, range_bits=4, range_chunks=8)
     for name, kw in (("build_withdraw_plan", small), ("build_deposit_plan", dict(k=11, height=3, range_bits=8, range_chunks=10)),
-                     ("build_new_account_plan", dict(k=10, range_bits=8, range_chunks=11)), ("build_withdraw_plan", {})):
+                     ("build_new_account_plan", dict(k=10, range_bits=8, range_chunks=11)), ("build_withdraw_plan", {}),
+                     ("build_phased_plan", {})):                         # three phases, four challenges
         yield name, getattr(C, name)(**kw)[0], getattr(C, name)(describe=True, **kw)[0]
 
 
@@ -32,7 +33,8 @@ def fuzz(seeds):
 def assert_equivalent(PL, name, plan_py, plan_c):
     a, b = PL.Plan(plan_py), PL.Plan(plan_c)
     for f in ("k", "num_advice", "num_fixed", "num_instance", "bf", "degree", "adv_q", "fix_q", "inst_q", "perm_cols", "consts",
-              "fixed", "wops", "instance_map", "n_winputs", "n_wscratch", "num_gates"):
+              "fixed", "wops", "instance_map", "n_winputs", "n_wscratch", "num_gates", "num_phases", "advice_phase",
+              "challenge_phase", "wops_end"):
         assert getattr(a, f) == getattr(b, f), f"{name}: {f}"
     assert all(np.array_equal(x, y) for x, y in zip(a.mapping, b.mapping)), f"{name}: permutation mapping"
     assert b.gate_slots <= a.gate_slots + 2, f"{name}: {b.gate_slots} slots against the builder's {a.gate_slots}"
@@ -41,7 +43,8 @@ def assert_equivalent(PL, name, plan_py, plan_c):
         av = [rnd.randrange(R) for _ in a.adv_q]
         fv = [rnd.randrange(R) for _ in a.fix_q]
         iv = rnd.randrange(R)
-        run = lambda prog, ns: list(PL.run_program_scalar(prog, ns, a.consts, lambda q: av[q], lambda q: fv[q], lambda q: iv))
+        cv = [rnd.randrange(R) for _ in a.challenge_phase]
+        run = lambda prog, ns: list(PL.run_program_scalar(prog, ns, a.consts, lambda q: av[q], lambda q: fv[q], lambda q: iv, cv))
         assert run(a.gate_prog, a.gate_slots) == run(b.gate_prog, b.gate_slots), f"{name}: gate program"
         assert len(a.lookups) == len(b.lookups)
         for (m1, pi1, si1, pt1, st1), (m2, pi2, si2, pt2, st2) in zip(a.lookups, b.lookups):
@@ -57,7 +60,7 @@ def test_compiled_description_equals_the_builders_plan():
         assert_equivalent(PL, name, plan_py, plan_c)
         assert shp.plan_min_k(plan_c) == shp.plan_min_k(plan_py)
         count += 1
-    assert count == 28
+    assert count == 29
 
 
 def test_malformed_descriptions_are_refused():

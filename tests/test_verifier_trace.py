@@ -80,8 +80,10 @@ def test_native_verifier_reproduces_the_contract(shp, oracle, gpu_ctx, case):
     for vec in case["vectors"]:
         p, ins = bytes.fromhex(vec["proof"]), [int(v, 16) for v in vec["instances"]]
         assert pk.verify(p, ins) == vec["accepted"], vec["label"]
-        ok, words = pk.verify_trace(p, ins)
+        ok, words, chal = pk.verify_trace(p, ins, with_challenges=True)
         assert ok == vec["accepted"]
+        if vec["trace"] is not None:
+            assert ["0x%064x" % c for c in chal] == vec["trace"].get("USER_CHALLENGES", []), vec["label"]
         if vec["trace"] is not None:
             for name, w in zip(WORDS, words):
                 assert "0x%064x" % w == vec["trace"][name], f'{vec["label"]}: {name}'

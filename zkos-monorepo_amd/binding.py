@@ -22,6 +22,10 @@ SHP_OK = 0
 BASIS_MONOMIAL, BASIS_LAGRANGE = 0, 1
 
 
+# shp_phase_fn: (user, phase, challenges, n_challenges) -> the caller's advice block, or NULL
+PHASE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t)
+
+
 class ShpError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libshielder_hip error {code}: {msg}")
@@ -450,14 +454,25 @@ class ProvingKey:
                                 C.byref(ok)))
         return bool(ok.value)
 
-    def verify_trace(self, proof: bytes, instances):
-        """shp_verify_trace: (accepted, [22 ints]) -- the words the reference's contract keeps (Halo2Verifier.sol:39-73)"""
+    def verify_trace(self, proof: bytes, instances, with_challenges=False):
+        """shp_verify_trace: (accepted, [22 ints]) -- the words the reference's contract keeps (Halo2Verifier.sol:39-73);
+        with_challenges: (accepted, [22 ints], the circuit's own challenges) for a circuit with several phases"""
         ins = b"".join(int(x).to_bytes(32, "little") for x in instances)
         ok = C.c_int32(0)
-        words = C.create_string_buffer(22 * 32)
+        nw = 22 + (self.phases()[1] if with_challenges else 0)
+        words = C.create_string_buffer(nw * 32)
         _check(lib().shp_verify_trace(self.h, C.c_char_p(proof), C.c_size_t(len(proof)), C.c_char_p(ins), C.c_size_t(len(instances)),
-                                      C.byref(ok), words, C.c_size_t(22 * 32)))
-        return bool(ok.value), [int.from_bytes(words.raw[32 * i:32 * i + 32], "big") for i in range(22)]
+                                      C.byref(ok), words, C.c_size_t(nw * 32)))
+        w = [int.from_bytes(words.raw[32 * i:32 * i + 32], "big") for i in range(nw)]
+        return (bool(ok.value), w[:22], w[22:]) if with_challenges else (bool(ok.value), w)
+
+    def phases(self):
+        """shp_pk_phases: (number of phases, number of challenges, phase of every advice column)"""
+        nph, nch, na = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib().shp_pk_phases(self.h, C.byref(nph), C.byref(nch), C.byref(na), None, C.c_size_t(0)))
+        cols = (C.c_uint32 * max(na.value, 1))()
+        _check(lib().shp_pk_phases(self.h, None, None, None, cols, C.c_size_t(na.value)))
+        return nph.value, nch.value, list(cols)[:na.value]
 
     def gate_compiled(self) -> bool:
         """True when the key's gate expressions run as a kernel compiled ahead of time (a plan the library ships)"""
@@ -539,6 +554,39 @@ class Prover:
                                         C.c_size_t(d.shape[0] if d is not None else 0),
                                         C.c_char_p(seed) if seed is not None else None, proof, C.c_size_t(self.pk.proof_len),
                                         C.byref(plen)))
+        return proof.raw[:plen.value]
+
+    def prove_assigned_phased(self, synthesize, instances, assigned_rows=0, seed: bytes = None, draws=None):
+        """generate_proof for a circuit with several phases whose columns the caller synthesises: `synthesize(phase,
+        challenges)` is called once per phase with the challenges squeezed so far (ints; those of later phases are 0) and
+        returns the advice block ((A, n, 4) uint64 Montgomery limbs) of which the library reads that phase's columns"""
+        ins = np.ascontiguousarray(instances, dtype=np.uint64).reshape(-1, 4)
+        d = None if draws is None else np.ascontiguousarray(draws, dtype=np.uint64)
+        keep, failure = [], []
+
+        @PHASE_FN
+        def trampoline(_user, phase, chal_ptr, n_chal):
+            try:
+                limbs = np.ctypeslib.as_array(C.cast(chal_ptr, C.POINTER(C.c_uint64)), shape=(n_chal, 4)).copy() if n_chal else np.zeros((0, 4), np.uint64)
+                chal = [int.from_bytes(fr_to_le32(limbs[i]), "little") for i in range(n_chal)]
+                block = np.ascontiguousarray(synthesize(int(phase), chal), dtype=np.uint64)
+                keep[:] = [block]                      # valid until the next call
+                return block.ctypes.data
+            except BaseException as e:                 # an exception must not cross the C frames: the proof is abandoned
+                failure.append(e)
+                return None
+        ncols, nrows = len(self.pk.phases()[2]), 1 << self.pk.k
+        proof = C.create_string_buffer(self.pk.proof_len)
+        plen = C.c_size_t()
+        rc = lib().shp_prove_assigned_phased(self.h, trampoline, None, C.c_size_t(ncols), C.c_size_t(nrows), C.c_size_t(assigned_rows),
+                                             ins.ctypes.data_as(C.c_void_p), C.c_size_t(ins.shape[0]),
+                                             d.ctypes.data_as(C.c_void_p) if d is not None else None,
+                                             C.c_size_t(d.shape[0] if d is not None else 0),
+                                             C.c_char_p(seed) if seed is not None else None, proof, C.c_size_t(self.pk.proof_len),
+                                             C.byref(plen))
+        if failure:
+            raise failure[0]
+        _check(rc)
         return proof.raw[:plen.value]
 
     def mode(self, throughput: bool):

@@ -202,8 +202,9 @@ class PlanBuilder:
     def num_phases(self):
         return max(self.advice_phase + [0]) + 1
 
-    def _phase_tail(self):
-        """what version 2 appends (empty for a single-phase circuit without challenges)"""
+    def _phase_tail(self, description=False):
+        """what version 2 appends (None for a single-phase circuit without challenges); the description carries the number of
+        challenges in its header instead"""
         P = self.num_phases()
         if P == 1 and not self.challenge_phase:
             return None
@@ -213,7 +214,7 @@ class PlanBuilder:
         ends = list(self.wops_end) + [len(self.wops)] * (P - len(self.wops_end))
         assert len(ends) == P and ends == sorted(ends) and ends[-1] == len(self.wops), "next_phase() calls do not match the phases"
         assert all(self.advice_phase[c] == 0 for c, _ in self.instance_map), "public inputs are first-phase cells"
-        return struct.pack("<2I", P, len(self.challenge_phase)) + struct.pack("<%dI" % self.num_advice, *self.advice_phase) + \
+        return struct.pack("<I", P) + (b"" if description else struct.pack("<I", len(self.challenge_phase))) + struct.pack("<%dI" % self.num_advice, *self.advice_phase) + \
             struct.pack("<%dI" % len(self.challenge_phase), *self.challenge_phase) + struct.pack("<%dI" % P, *ends)
 
     def fixed_column(self):
@@ -282,7 +283,7 @@ class PlanBuilder:
         fixed values, copy constraints, witness program -- no compiled programs, no degree, no mapping."""
         self.build()                                   # registers every query and constant (idempotent)
         nodes, ids = [], {}
-        KIND = {"const": 0, "adv": 1, "fix": 2, "inst": 3, "add": 4, "sub": 5, "mul": 6, "neg": 7, "chal": 8}
+        KIND = {"const": 0, "adv": 1, "fix": 2, "inst": 3, "add": 4, "sub": 5, "mul": 6, "neg": 7, "chal": 9}
 
         def node(e):
             k = id(e)
@@ -302,7 +303,7 @@ class PlanBuilder:
                 elif cur.kind == "adv": rec = (1, self.adv_query(*cur.args), 0)
                 elif cur.kind == "fix": rec = (2, self.fix_query(*cur.args), 0)
                 elif cur.kind == "inst": rec = (3, self.inst_query(*cur.args), 0)
-                elif cur.kind == "chal": rec = (8, cur.args[0], 0)
+                elif cur.kind == "chal": rec = (9, cur.args[0], 0)
                 elif cur.kind == "neg": rec = (7, ids[id(kids[0])], 0)
                 else: rec = (KIND[cur.kind], ids[id(kids[0])], ids[id(kids[1])])
                 ids[id(cur)] = len(nodes)
@@ -317,10 +318,10 @@ class PlanBuilder:
         for op, dc, dr, ac, ar, bc, br, imm in self.wops:
             d, a, b_ = cell((dc, dr)), cell((ac, ar)), cell((bc, br))
             wops.append((op, d[0], d[1], a[0], a[1], b_[0], b_[1], imm))
-        tail = self._phase_tail()
+        tail = self._phase_tail(description=True)
         hdr = [1 if tail is None else 2, self.k, self.num_advice, self.num_fixed, self.num_instance, len(self.adv_q), len(self.fix_q),
                len(self.inst_q), len(self.perm_cols), len(self.consts), len(nodes), len(gates), len(lookups), len(self.copies), 0,
-               self.n_winputs, len(wops), self.n_wscratch, len(self.instance_map), 0]
+               self.n_winputs, len(wops), self.n_wscratch, len(self.instance_map), len(self.challenge_phase)]
         out = bytearray(b"SHCD" + struct.pack("<20I", *hdr))
         for lst in (self.adv_q, self.fix_q, self.inst_q):
             for c, r in lst:

@@ -1,7 +1,8 @@
-// Circuit plan (version 1) parser: the constraint system + fixed data + witness program the
+// Circuit plan parser: the constraint system + fixed data + witness program the
 // prover is driven by.  Layout documented in zkos-monorepo_amd/circuits/builder.py;
 // the fields are the quantities the reference's verifier generator reads off a halo2
 // ConstraintSystem (/root/reference/crates/halo2-verifier/src/lib/codegen/util.rs:42-131).
+// Version 2 adds phases: advice columns assigned after challenges have been squeezed (util.rs:70-96, 133-165).
 #pragma once
 #include <string.h>
 
@@ -14,8 +15,10 @@
 
 namespace shp {
 
-enum { OP_CONST = 0, OP_ADV, OP_FIX, OP_INST, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_OUT };
-enum { W_INPUT = 0, W_CONST, W_COPY, W_ADD, W_SUB, W_MUL, W_ADDC, W_MULC, W_POW7, W_BITS, W_SHR };
+// OP_CHAL (a = challenge index) exists in plans only: the device programs read the proof's challenges as constants
+// placed behind the plan's own (PlanData::device_prog)
+enum { OP_CONST = 0, OP_ADV, OP_FIX, OP_INST, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_OUT, OP_CHAL };
+enum { W_INPUT = 0, W_CONST, W_COPY, W_ADD, W_SUB, W_MUL, W_ADDC, W_MULC, W_POW7, W_BITS, W_SHR, W_CHAL };
 enum { COL_ADVICE = 0, COL_FIXED = 1, COL_INSTANCE = 2 };
 
 struct Instr { uint32_t op, dst, a, b; };
@@ -38,6 +41,11 @@ struct PlanData {
     std::vector<std::vector<uint32_t>> mapping;                  // per permutation column: target col * n + row
     std::vector<WOp> wops;
     std::vector<std::pair<uint32_t, uint32_t>> instance_map;     // advice cell of public input i
+    // phases (version 2; a version-1 plan has one phase, no challenges)
+    uint32_t num_phases = 1;
+    std::vector<uint32_t> advice_phase;                          // per advice column
+    std::vector<uint32_t> challenge_phase;                       // challenge i is squeezed after the commitments of this phase
+    std::vector<uint32_t> wops_end;                              // witness ops of phase p: [wops_end[p-1], wops_end[p])
     uint8_t plan_hash[32];
     // derived
     uint32_t n = 0, usable = 0, ext_k = 0, chunk = 0, num_sets = 0;
@@ -59,13 +67,32 @@ struct PlanData {
     // inputs -- and the same plan laid out for another k (rows keep their index, the permutation mapping is re-encoded)
     uint32_t min_k() const;
     PlanData retarget(uint32_t new_k) const;
+    bool phased() const { return num_phases > 1 || !challenge_phase.empty(); }
+    uint32_t wops_begin(uint32_t phase) const { return phase ? wops_end[phase - 1] : 0; }
+    // maximal runs [first, first + count) of consecutive advice columns that belong to `phase`
+    std::vector<std::pair<uint32_t, uint32_t>> phase_runs(uint32_t phase) const {
+        std::vector<std::pair<uint32_t, uint32_t>> runs;
+        for (uint32_t c = 0; c < num_advice; c++) {
+            if (advice_phase[c] != phase) continue;
+            if (!runs.empty() && runs.back().first + runs.back().second == c) runs.back().second++;
+            else runs.push_back({c, 1});
+        }
+        return runs;
+    }
+    // a program as the device kernels read it: challenge i is constant consts.size() + i of the lane's own table
+    std::vector<Instr> device_prog(const std::vector<Instr>& prog) const {
+        std::vector<Instr> out = prog;
+        for (Instr& in : out)
+            if (in.op == OP_CHAL) { in.op = OP_CONST; in.a += (uint32_t)consts.size(); }
+        return out;
+    }
 };
 
 inline void PlanData::parse(const uint8_t* d, size_t len) {
     SHP_REQUIRE(len >= 84 && memcmp(d, "SHPL", 4) == 0, SHP_ERR_FORMAT, "plan: bad magic");
     uint32_t h[20];
     memcpy(h, d + 4, 80);
-    SHP_REQUIRE(h[0] == 1, SHP_ERR_FORMAT, "plan: unsupported version");
+    SHP_REQUIRE(h[0] == 1 || h[0] == 2, SHP_ERR_FORMAT, "plan: unsupported version");
     k = h[1]; num_advice = h[2]; num_fixed = h[3]; num_instance = h[4]; bf = h[5]; degree = h[6];
     const uint32_t naq = h[7], nfq = h[8], niq = h[9], npc = h[10], ncst = h[11], ngi = h[12];
     gate_slots = h[13]; num_gates = h[14];
@@ -114,9 +141,10 @@ inline void PlanData::parse(const uint8_t* d, size_t len) {
         memcpy(v.data(), d + off, (size_t)cnt * 16);
         off += (size_t)cnt * 16;
         for (auto& in : v) {
-            SHP_REQUIRE(in.op <= OP_OUT, SHP_ERR_FORMAT, "plan: bad opcode");
+            SHP_REQUIRE(in.op <= OP_CHAL, SHP_ERR_FORMAT, "plan: bad opcode");
             bool ok = in.dst < slots || in.op == OP_OUT;
             if (in.op == OP_CONST) ok = ok && in.a < ncst;
+            else if (in.op == OP_CHAL) ok = ok && h[0] == 2;     // the index is checked once the challenges are known
             else if (in.op == OP_ADV) ok = ok && in.a < naq;
             else if (in.op == OP_FIX) ok = ok && in.a < nfq;
             else if (in.op == OP_INST) ok = ok && in.a < niq;
@@ -170,8 +198,9 @@ inline void PlanData::parse(const uint8_t* d, size_t len) {
         auto cell_ok = [&](uint32_t c, uint32_t r) {
             return (c < num_advice && r < n) || (c == num_advice && r < (n_wscratch ? n_wscratch : 1));
         };
-        bool ok = w.op <= W_SHR && cell_ok(w.dc, w.dr);
+        bool ok = w.op <= W_CHAL && cell_ok(w.dc, w.dr);
         if (w.op == W_INPUT) ok = ok && w.imm < n_winputs;
+        else if (w.op == W_CHAL) ok = ok && h[0] == 2;
         else if (w.op == W_CONST) ok = ok && w.imm < ncst;
         else {
             ok = ok && cell_ok(w.ac, w.ar);
@@ -188,6 +217,59 @@ inline void PlanData::parse(const uint8_t* d, size_t len) {
         memcpy(&instance_map[i].second, d + off + 4, 4);
         off += 8;
         SHP_REQUIRE(instance_map[i].first < num_advice && instance_map[i].second < n, SHP_ERR_FORMAT, "plan: bad instance cell");
+    }
+    num_phases = 1;
+    advice_phase.assign(num_advice, 0);
+    challenge_phase.clear();
+    wops_end.assign(1, nwo);
+    if (h[0] == 2) {
+        need(8);
+        uint32_t nch;
+        memcpy(&num_phases, d + off, 4);
+        memcpy(&nch, d + off + 4, 4);
+        off += 8;
+        SHP_REQUIRE(num_phases >= 1 && num_phases <= 8 && nch <= 64, SHP_ERR_FORMAT, "plan: implausible phase / challenge counts");
+        auto rd_u32s = [&](std::vector<uint32_t>& v, uint32_t cnt) {
+            need((size_t)cnt * 4);
+            v.resize(cnt);
+            if (cnt) memcpy(v.data(), d + off, (size_t)cnt * 4);
+            off += (size_t)cnt * 4;
+        };
+        rd_u32s(advice_phase, num_advice);
+        rd_u32s(challenge_phase, nch);
+        rd_u32s(wops_end, num_phases);
+        std::vector<uint32_t> cols(num_phases, 0), chals(num_phases, 0);
+        for (uint32_t ph : advice_phase) {
+            SHP_REQUIRE(ph < num_phases, SHP_ERR_FORMAT, "plan: advice column in a phase that does not exist");
+            cols[ph]++;
+        }
+        for (uint32_t ph : challenge_phase) {
+            SHP_REQUIRE(ph < num_phases, SHP_ERR_FORMAT, "plan: challenge after a phase that does not exist");
+            chals[ph]++;
+        }
+        for (uint32_t ph = 0; ph < num_phases; ph++) {
+            SHP_REQUIRE(cols[ph] >= 1, SHP_ERR_FORMAT, "plan: a phase without advice columns");
+            // the verifier squeezes at least one challenge after every phase but the last (Halo2Verifier.sol:278-281)
+            SHP_REQUIRE(ph + 1 == num_phases || chals[ph] >= 1, SHP_ERR_FORMAT, "plan: a phase before the last draws no challenge");
+            SHP_REQUIRE(wops_end[ph] <= nwo && (!ph || wops_end[ph - 1] <= wops_end[ph]), SHP_ERR_FORMAT, "plan: bad phase bounds of the witness program");
+        }
+        SHP_REQUIRE(wops_end[num_phases - 1] == nwo, SHP_ERR_FORMAT, "plan: witness ops behind the last phase");
+        // an op of phase p may read the challenges of earlier phases only, and writes advice cells of its own phase only
+        // (halo2 records the advice of the current phase and hands out the challenges squeezed before it)
+        for (uint32_t ph = 0; ph < num_phases; ph++)
+            for (uint32_t i = wops_begin(ph); i < wops_end[ph]; i++) {
+                const WOp& w = wops[i];
+                if (w.op == W_CHAL) SHP_REQUIRE(w.imm < nch && challenge_phase[w.imm] < ph, SHP_ERR_FORMAT, "plan: witness op reads a challenge that is not known yet");
+                if (w.dc < num_advice) SHP_REQUIRE(advice_phase[w.dc] == ph, SHP_ERR_FORMAT, "plan: witness op writes a column of another phase");
+            }
+        auto check_prog = [&](const std::vector<Instr>& v) {
+            for (const Instr& in : v)
+                if (in.op == OP_CHAL) SHP_REQUIRE(in.a < nch, SHP_ERR_FORMAT, "plan: bad challenge index");
+        };
+        check_prog(gate_prog);
+        for (const auto& lk : lookups) { check_prog(lk.in_prog); check_prog(lk.tab_prog); }
+        for (const auto& im : instance_map)
+            SHP_REQUIRE(advice_phase[im.first] == 0, SHP_ERR_FORMAT, "plan: a public input is not a first-phase cell");
     }
     SHP_REQUIRE(off == len && nim == num_instance, SHP_ERR_FORMAT, "plan: trailing bytes or instance count mismatch");
     usable = n - (bf + 1);
@@ -211,7 +293,7 @@ inline std::vector<uint8_t> PlanData::serialize() const {
         const Fr raw = v.to_raw();
         put(raw.l, 32);
     };
-    const uint32_t h[20] = {1, k, num_advice, num_fixed, num_instance, bf, degree, (uint32_t)adv_q.size(), (uint32_t)fix_q.size(),
+    const uint32_t h[20] = {phased() ? 2u : 1u, k, num_advice, num_fixed, num_instance, bf, degree, (uint32_t)adv_q.size(), (uint32_t)fix_q.size(),
                             (uint32_t)inst_q.size(), (uint32_t)perm_cols.size(), (uint32_t)consts.size(), (uint32_t)gate_prog.size(),
                             gate_slots, num_gates, (uint32_t)lookups.size(), n_winputs, (uint32_t)wops.size(), n_wscratch,
                             (uint32_t)instance_map.size()};
@@ -236,6 +318,14 @@ inline std::vector<uint8_t> PlanData::serialize() const {
     for (const auto& m : mapping) put(m.data(), m.size() * 4);
     if (!wops.empty()) put(wops.data(), wops.size() * sizeof(WOp));
     for (const auto& im : instance_map) { put(&im.first, 4); put(&im.second, 4); }
+    if (phased()) {
+        const uint32_t nch = (uint32_t)challenge_phase.size();
+        put(&num_phases, 4);
+        put(&nch, 4);
+        put(advice_phase.data(), advice_phase.size() * 4);
+        if (nch) put(challenge_phase.data(), (size_t)nch * 4);
+        put(wops_end.data(), wops_end.size() * 4);
+    }
     return out;
 }
 

@@ -12,22 +12,26 @@
 // prog_fold_*_kernel, a reload is one L2-resident read), and the permutation mapping built from the copy constraints
 // the way halo2's permutation::keygen::Assembly::copy joins cycles.
 //
-// Circuit description, little endian ("SHCD", version 1):
+// Circuit description, little endian ("SHCD", version 1; version 2 for a circuit with several phases or challenges):
 //   header  20 x u32: version, k, num_advice, num_fixed, num_instance, n_adv_q, n_fix_q, n_inst_q, n_perm_cols,
 //                     n_consts, n_nodes, n_gates, n_lookups, n_copies, has_mapping, n_winputs, n_wops, n_wscratch,
-//                     n_instance_map, reserved (0)
+//                     n_instance_map, n_challenges (version 1: 0)
 //   advice / fixed / instance queries   (u32 column, i32 rotation) each, in the constraint system's order
 //   permutation columns                 (u32 type: 0 advice 1 fixed 2 instance, u32 index) each
 //   constants                           32 bytes little-endian canonical each
 //   nodes                               (u32 kind, u32 a, u32 b) each, children before parents:
 //                                       0 CONST(a = constant) 1 ADVICE(a = query) 2 FIXED(a = query) 3 INSTANCE(a = query)
 //                                       4 SUM(a, b) 5 DIFFERENCE(a, b) 6 PRODUCT(a, b) 7 NEGATED(a) 8 SCALED(a, b = constant)
+//                                       9 CHALLENGE(a = challenge index; version 2)
 //   gates                               u32 root node each, in gate / polynomial order
 //   lookups                             u32 m, m input roots, m table roots each
 //   fixed columns                       per column: u32 nnz, then (u32 row, 32-byte value) each
 //   copy constraints (has_mapping = 0)  (u32 type, index, row) x 2 each   |   mapping (has_mapping = 1) u32[2^k] per column
 //   witness program                     8 x u32 per op (the plan's own encoding; may be empty: shp_prove_assigned)
 //   instance map                        (u32 advice column, u32 row) per public input
+//   phases (version 2)                  u32 num_phases, then the phase of every advice column (cs.advice_column_phase()), the
+//                                       phase of every challenge (cs.challenge_phase()), the end of every phase in the witness
+//                                       program (u32 each)
 // Host code only; the .hip suffix is for the build.
 #include <string.h>
 
@@ -39,7 +43,7 @@
 namespace {
 using namespace shp;
 
-enum { N_CONST = 0, N_ADV, N_FIX, N_INST, N_SUM, N_DIFF, N_PROD, N_NEG, N_SCALED };
+enum { N_CONST = 0, N_ADV, N_FIX, N_INST, N_SUM, N_DIFF, N_PROD, N_NEG, N_SCALED, N_CHAL };
 
 struct Node { uint32_t kind, a, b; };
 
@@ -68,7 +72,7 @@ struct Compiler {
         if (it != intern.end()) return it->second;
         uint32_t deg = 0;
         switch (nd.kind) {
-            case N_CONST: deg = 0; break;
+            case N_CONST: case N_CHAL: deg = 0; break;
             case N_ADV: case N_FIX: case N_INST: deg = 1; break;
             case N_SUM: case N_DIFF: deg = std::max(degree[nd.a], degree[nd.b]); break;
             case N_PROD: deg = degree[nd.a] + degree[nd.b]; break;
@@ -79,7 +83,7 @@ struct Compiler {
         intern[key] = (uint32_t)nodes.size() - 1;
         return (uint32_t)nodes.size() - 1;
     }
-    static bool leaf(uint32_t kind) { return kind <= N_INST; }
+    static bool leaf(uint32_t kind) { return kind <= N_INST || kind == N_CHAL; }
 
     // roots -> program (OUT after each root, in order) and the number of slots it needs
     void compile(const std::vector<uint32_t>& roots, std::vector<Instr>& prog, uint32_t& nslots) const {
@@ -159,6 +163,7 @@ struct Compiler {
                 case N_ADV: prog.push_back(Instr{OP_ADV, dst, nd.a, 0}); break;
                 case N_FIX: prog.push_back(Instr{OP_FIX, dst, nd.a, 0}); break;
                 case N_INST: prog.push_back(Instr{OP_INST, dst, nd.a, 0}); break;
+                case N_CHAL: prog.push_back(Instr{OP_CHAL, dst, nd.a, 0}); break;
                 case N_SUM: prog.push_back(Instr{OP_ADD, dst, ka, kb}); break;
                 case N_DIFF: prog.push_back(Instr{OP_SUB, dst, ka, kb}); break;
                 case N_PROD: prog.push_back(Instr{OP_MUL, dst, ka, kb}); break;
@@ -174,7 +179,8 @@ void compile_description(const uint8_t* d, size_t len, std::vector<uint8_t>& out
     Reader r{d, len, 4};
     uint32_t h[20];
     for (auto& v : h) v = r.u32();
-    SHP_REQUIRE(h[0] == 1 && h[19] == 0, SHP_ERR_FORMAT, "circuit description: unsupported version");
+    SHP_REQUIRE((h[0] == 1 && h[19] == 0) || (h[0] == 2 && h[19] <= 64), SHP_ERR_FORMAT, "circuit description: unsupported version");
+    const uint32_t nch = h[19];
     PlanData P;
     P.k = h[1]; P.num_advice = h[2]; P.num_fixed = h[3]; P.num_instance = h[4];
     const uint32_t naq = h[5], nfq = h[6], niq = h[7], npc = h[8], ncst = h[9], nn = h[10], ng = h[11], nlk = h[12], ncp = h[13],
@@ -213,19 +219,20 @@ void compile_description(const uint8_t* d, size_t len, std::vector<uint8_t>& out
     C.canon.resize(nn);
     for (uint32_t i = 0; i < nn; i++) {
         Node nd{r.u32(), r.u32(), r.u32()};
-        SHP_REQUIRE(nd.kind <= N_SCALED, SHP_ERR_FORMAT, "circuit description: bad node kind");
+        SHP_REQUIRE(nd.kind <= N_CHAL, SHP_ERR_FORMAT, "circuit description: bad node kind");
         bool ok = true;
         switch (nd.kind) {
             case N_CONST: ok = nd.a < ncst; break;
             case N_ADV: ok = nd.a < naq; break;
             case N_FIX: ok = nd.a < nfq; break;
             case N_INST: ok = nd.a < niq; break;
+            case N_CHAL: ok = nd.a < nch; break;
             case N_NEG: ok = nd.a < i; if (ok) nd.a = C.canon[nd.a]; nd.b = 0; break;
             case N_SCALED: ok = nd.a < i && nd.b < ncst; if (ok) nd.a = C.canon[nd.a]; break;
             default: ok = nd.a < i && nd.b < i; if (ok) { nd.a = C.canon[nd.a]; nd.b = C.canon[nd.b]; } break;
         }
         SHP_REQUIRE(ok, SHP_ERR_FORMAT, "circuit description: node refers to a later node, query or constant out of range");
-        if (nd.kind <= N_INST) nd.b = 0;
+        if (Compiler::leaf(nd.kind)) nd.b = 0;
         C.canon[i] = C.add(nd);
     }
     auto root = [&]() {
@@ -316,6 +323,17 @@ void compile_description(const uint8_t* d, size_t len, std::vector<uint8_t>& out
     r.off += (size_t)nwo * 32;
     P.instance_map.resize(nim);
     for (auto& im : P.instance_map) { im.first = r.u32(); im.second = r.u32(); }
+    P.advice_phase.assign(P.num_advice, 0);
+    P.wops_end.assign(1, nwo);
+    if (h[0] == 2) {
+        P.num_phases = r.u32();
+        SHP_REQUIRE(P.num_phases >= 1 && P.num_phases <= 8, SHP_ERR_FORMAT, "circuit description: implausible number of phases");
+        for (auto& v : P.advice_phase) v = r.u32();
+        P.challenge_phase.resize(nch);
+        for (auto& v : P.challenge_phase) v = r.u32();
+        P.wops_end.resize(P.num_phases);
+        for (auto& v : P.wops_end) v = r.u32();
+    }
     SHP_REQUIRE(r.off == len, SHP_ERR_FORMAT, "circuit description: trailing bytes");
     out = P.serialize();
     PlanData check;                                   // everything parse() validates (operands, cells, counts) holds for the result

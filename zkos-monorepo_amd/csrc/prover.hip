@@ -158,6 +158,7 @@ static uint64_t gate_program_hash(const PlanData& P) {
 }
 
 static GateKernelFn find_gate_kernel(const PlanData& P) {
+    if (P.phased()) return nullptr;                  // the generated kernels know nothing of per-proof challenges
     const char* e = getenv("SHP_GATE_AOT");
     if (e && e[0] == '0') return nullptr;                    // A/B and tests: always interpret
     const uint64_t h = gate_program_hash(P);
@@ -200,6 +201,7 @@ static uint64_t quotient_hash(const PlanData& P) {
 }
 
 static QuotientKernelFn find_quotient_kernel(const PlanData& P) {
+    if (P.phased()) return nullptr;
     for (const char* name : {"SHP_GATE_AOT", "SHP_QUOT29"}) {       // A/B and tests: the separate radix-2^256 kernels
         const char* e = getenv(name);
         if (e && e[0] == '0') return nullptr;
@@ -375,7 +377,13 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
             for (uint32_t j = 0; j < nc; j++) I[(size_t)m * nc + j] = I[(size_t)m * nc + j] * ti[j];
         pk->vinv = pk->dupload(I);                 // h_m = sum_j vinv[m][j] * y_j / (c_j^n - 1)
     }
-    pk->consts = pk->dupload(P.consts);
+    {
+        // a circuit with several phases reads its challenges as constants behind the plan's own: this table is the template
+        // every proving lane copies and completes per proof
+        std::vector<Fr> cst(P.consts);
+        cst.resize(P.consts.size() + P.challenge_phase.size(), Fr::zero());
+        pk->consts = pk->dupload(cst);
+    }
     if (pk->quot_fn) {
         std::vector<Fr> c29(P.consts);
         for (Fr& c : c29) c = c * radix_shift;
@@ -385,11 +393,11 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
             for (uint32_t i = 0; i < nq; i++) dx[(size_t)c * nq + i] = pk->delta_pow[c] * xe[i];     // xe carries the 32
         pk->dx_ext = pk->dupload(dx);
     }
-    pk->gate_prog = pk->dupload(P.gate_prog);
+    pk->gate_prog = pk->dupload(P.device_prog(P.gate_prog));
     pk->gate_fn = find_gate_kernel(P);
     for (auto& lk : P.lookups) {
-        pk->lk_in_prog.push_back(pk->dupload(lk.in_prog));
-        pk->lk_tab_prog.push_back(pk->dupload(lk.tab_prog));
+        pk->lk_in_prog.push_back(pk->dupload(P.device_prog(lk.in_prog)));
+        pk->lk_tab_prog.push_back(pk->dupload(P.device_prog(lk.tab_prog)));
     }
     pk->adv_q = pk->dupload(P.adv_q);
     pk->fix_q = pk->dupload(P.fix_q);
@@ -443,7 +451,7 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
 // P1: the plan's witness program over Montgomery values (the reference's `synthesize`).
 // Ops [lo, hi) with a caller-owned scratch row.
 static void run_witness_range(const PlanData& P, const std::vector<Fr>& inputs, Fr* grid /* [A][n], pinned */, Fr* scratch,
-                              uint32_t lo, uint32_t hi) {
+                              uint32_t lo, uint32_t hi, const Fr* chal = nullptr /* the challenges squeezed so far */) {
     const uint32_t A = P.num_advice, n = P.n;
     auto cell = [&](uint32_t c, uint32_t r) -> Fr& { return c == A ? scratch[r] : grid[(size_t)c * n + r]; };
     for (uint32_t i = lo; i < hi; i++) {
@@ -452,6 +460,10 @@ static void run_witness_range(const PlanData& P, const std::vector<Fr>& inputs, 
         switch (w.op) {
             case W_INPUT: v = inputs[w.imm]; break;
             case W_CONST: v = P.consts[w.imm]; break;
+            case W_CHAL:
+                if (!chal) throw Error(SHP_ERR_FORMAT, "witness: challenge read outside a proof");
+                v = chal[w.imm];
+                break;
             case W_COPY: v = cell(w.ac, w.ar); break;
             case W_ADD: v = cell(w.ac, w.ar) + cell(w.bc, w.br); break;
             case W_SUB: v = cell(w.ac, w.ar) - cell(w.bc, w.br); break;
@@ -736,6 +748,7 @@ struct shp_prover {
     }
     // a pool's cross-lane MSM combiner (null: this lane launches its own commitments) and the event that hands
     // the lane's stream position over to it
+    Fr* consts_lane = nullptr;             // several phases: the key's constants + this proof's challenges
     bool throughput = false;               // shp_prover_mode(1): scheduling choices of a pool lane
     bool keep_phases = false;
     std::vector<std::pair<const char*, double>> last_phases;   // host phase clock of the last proof (profiling on)
@@ -768,6 +781,7 @@ struct shp_prover {
 static void set_witness_threads(shp_prover* pr, uint32_t threads) {
     threads = std::max<uint32_t>(1, std::min<uint32_t>(threads, 16));
     pr->wworkers.reset();
+    if (pr->pk->plan.phased()) return;     // a phase's part of the program runs in order on the calling thread
     pr->wsched.build(pr->pk->plan, threads);
     if (pr->wsched.n_threads > 1 && !pr->wsched.plan.empty())
         pr->wworkers.reset(new WitnessWorkers(pr->wsched.n_threads, pr->pk->plan.n_wscratch));
@@ -831,6 +845,11 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->msm_ws.timers = &pr->timers;
     pr->msm_ws.poll_results = poll_results_enabled();       // a new lane is a latency lane until shp_prover_mode says otherwise
     pr->wscratch.assign(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
+    if (P.phased()) {
+        const size_t cnt = P.consts.size() + P.challenge_phase.size();
+        pr->consts_lane = pr->dalloc<Fr>(cnt);
+        SHP_HIP(hipMemcpyAsync(pr->consts_lane, pk->consts, cnt * sizeof(Fr), hipMemcpyDeviceToDevice, pr->st));
+    }
     {
         const char* e = getenv("SHP_WITNESS_THREADS");
         set_witness_threads(pr.get(), e && *e ? (uint32_t)atoi(e) : 8);   // 14 independent permutations: 215 us at 4, 175 at 8
@@ -914,13 +933,17 @@ struct ProveInput {
     uint32_t assigned_rows = 0;              //   rows [assigned_rows, usable) of every column are zero and not read
     const Fr* instances = nullptr;           //   public inputs, Montgomery
     size_t n_instances = 0;
+    // several phases: the caller synthesises phase by phase (halo2 calls `synthesize` once per phase with the challenges
+    // squeezed so far); returns its [A][n] columns, of which those of `phase` are read, or null to give up
+    const uint64_t* (*phase_fn)(void* user, uint32_t phase, const uint64_t* challenges, size_t n_challenges) = nullptr;
+    void* phase_user = nullptr;
     const uint8_t* seed = nullptr;           // 32 bytes, or
     const Fr* draws = nullptr;               // n_draws field elements in draw order (Montgomery)
     size_t n_draws = 0;
 };
 
-// Fr::random draws one proof consumes, in this order: per advice column its bf+1 blinding rows (column-major), A unused
-// commitment blinds; per lookup bf+1 permuted-input rows, bf+1 permuted-table rows, 2 unused blinds; per grand product
+// Fr::random draws one proof consumes, in this order: per phase (a circuit without phases has one), per advice column of the
+// phase its bf+1 blinding rows (column-major), then one unused commitment blind per column of the phase; per lookup bf+1 permuted-input rows, bf+1 permuted-table rows, 2 unused blinds; per grand product
 // (permutation sets, then lookups) bf rows + 1 unused blind; the n coefficients of the random polynomial + 1 unused blind;
 // one unused blind per quotient piece.
 static uint64_t randomness_len(const PlanData& P) {
@@ -941,7 +964,10 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     const uint32_t A = P.num_advice, L = (uint32_t)P.lookups.size(), S = P.num_sets, NV = pk->NV;
     const uint32_t PC = (uint32_t)P.perm_cols.size(), F = P.num_fixed;
     const uint32_t nb = bf + 1;
-    const bool assigned = in.advice != nullptr;
+    const bool assigned = in.advice != nullptr || in.phase_fn != nullptr;
+    const bool phased = P.phased();
+    SHP_REQUIRE(!(phased && in.advice && P.num_phases > 1), SHP_ERR_INVALID_ARG,
+                "prove_assigned: a circuit with several phases is synthesised phase by phase (shp_prove_assigned_phased)");
     if (assigned) {
         SHP_REQUIRE(in.assigned_rows <= u, SHP_ERR_INVALID_ARG, "prove_assigned: more assigned rows than usable rows");
         SHP_REQUIRE(in.n_instances == P.num_instance && (in.instances || !in.n_instances), SHP_ERR_INVALID_ARG,
@@ -1112,81 +1138,178 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     // ---- P0/P1: witness, blinding rows, instance column
     std::vector<Fr> instances;
     Fr* const grid = pr->h_grid;                        // pinned: [A][n] advice, then the instance column
-    uint32_t rows_now;                                  // leading rows of the advice columns that this proof may fill
-    if (assigned) {
-        // the caller's columns: rows [0, assigned_rows) through the pinned grid (asynchronous copies from pageable memory
-        // serialise the streams of concurrent lanes), values validated on the way
-        rows_now = in.assigned_rows ? in.assigned_rows : u;
-        for (uint32_t c = 0; c < A; c++) {
-            const Fr* src = in.advice + (size_t)c * n;
-            Fr* dst = grid + (size_t)c * n;
-            for (uint32_t r = 0; r < rows_now; r++) {
-                SHP_REQUIRE(!src[r].geq_p(), SHP_ERR_FORMAT, "prove_assigned: advice value is not a canonical field element");
-                dst[r] = src[r];
-            }
-        }
-        pr->grid_foreign = true;
-        instances.assign(in.instances, in.instances + in.n_instances);
-        for (auto& v : instances) SHP_REQUIRE(!v.geq_p(), SHP_ERR_FORMAT, "prove_assigned: public input is not a canonical field element");
-    } else {
-        std::vector<Fr> inputs(n_inputs);
-        for (size_t i = 0; i < n_inputs; i++) {
-            Fr raw;
-            memcpy(raw.l, inputs_le32 + 32 * i, 32);
-            SHP_REQUIRE(!raw.geq_p(), SHP_ERR_FORMAT, "prove: witness input is not a canonical field element");
-            inputs[i] = Fr::from_raw(raw);
-        }
-        if (pr->grid_foreign) {                         // an assigned-columns proof left other cells behind
-            memset(grid, 0, (size_t)A * n * sizeof(Fr));
-            pr->grid_foreign = false;
-        }
-        // no per-proof clearing: the program writes the same cells every time (fixed plan), the blinding rows are
-        // redrawn below, everything else has been zero since prover_create
-        if (pr->wworkers) pr->wworkers->run(P, inputs, grid, pr->wsched);
-        else run_witness_range(P, inputs, grid, pr->wscratch.data(), 0, (uint32_t)P.wops.size());
-        instances.resize(P.instance_map.size());
-        for (size_t i = 0; i < instances.size(); i++)
-            instances[i] = grid[(size_t)P.instance_map[i].first * n + P.instance_map[i].second];
-        rows_now = P.adv_rows;
-    }
-    pc.mark("run_witness");
-    for (uint32_t c = 0; c < A; c++)
-        for (uint32_t r = u; r < n; r++) grid[(size_t)c * n + r] = draw();
-    pc.mark("blind_draws");
-    ctr += A;                                           // one (unused) commitment blind per advice column
     Fr* const instcol = grid + (size_t)A * n;           // rows past the instances stay zero (cleared at creation)
-    for (size_t i = 0; i < instances.size(); i++) instcol[i] = instances[i];
-    // only the rows this proof assigns and the blinding rows travel; the rest is zero on both sides
-    if (A && rows_now < pr->dev_rows)                   // the previous proof filled more rows than this one
-        hipLaunchKernelGGL(zero_rows_kernel, dim3(ceil_div(pr->dev_rows - rows_now, 256), A), dim3(256), 0, st, V(0), (size_t)n,
-                           rows_now, pr->dev_rows);
-    pr->dev_rows = rows_now;
+    uint32_t rows_now;                                  // leading rows of the advice columns that this proof may fill
     Transcript tr(pk->vk_digest);
-    for (auto& v : instances) tr.common_scalar(v);
-    pc.mark("witness+upload");
-    // ---- P2: advice commitments.  The random polynomial of P7 depends on no challenge: its
-    // coefficients (blinding stream position known up front) and its commitment ride in the same launch.
     std::vector<G1Affine> pts(std::max<uint32_t>({A + 1, 2 * L, S + L + 1, P.degree}));
-    const MsmRows adv_rows{rows_now, u, n - u};       // assigned rows + blinding rows; the rest is zero
-    if (split_commits) {
-        // witness rows and instances in one dispatch; the random polynomial is on its way already
-        ingest(0, A + 1, rows_now, (uint32_t)instances.size());
-        commit_launch(pr->msm_ws, srs->msm_gl, V(0), A, pts.data(), &adv_rows);
-        msm_finish_jobs(pr->msm_ws_rand, st);
-        msm_finish_jobs(pr->msm_ws, st);
-    } else {
-        // witness rows, instances and the random polynomial reach the device in one dispatch (ingest_kernel), and the random
-        // polynomial's commitment rides in the advice columns' launch
-        ingest(0, A + 2, rows_now, (uint32_t)instances.size());
-        commit(srs->msm_gl, V(0), A, pts.data(), &adv_rows, srs->msm_g, pr->rand_poly, 1);
-        rand_comm = pts[A];
+    std::vector<Fr> chal(P.challenge_phase.size(), Fr::zero());
+    const Fr* advice_once = in.advice;                  // one phase, no challenge: the callback is asked once
+    if (!phased && in.phase_fn) {
+        advice_once = (const Fr*)in.phase_fn(in.phase_user, 0, nullptr, 0);
+        SHP_REQUIRE(advice_once, SHP_ERR_INVALID_ARG, "prove_assigned: the phase callback returned no columns");
     }
-    for (uint32_t c = 0; c < A; c++) tr.write_point(pts[c].x, pts[c].y);
+    if (!phased) {
+        if (assigned) {
+            // the caller's columns: rows [0, assigned_rows) through the pinned grid (asynchronous copies from pageable memory
+            // serialise the streams of concurrent lanes), values validated on the way
+            rows_now = in.assigned_rows ? in.assigned_rows : u;
+            for (uint32_t c = 0; c < A; c++) {
+                const Fr* src = advice_once + (size_t)c * n;
+                Fr* dst = grid + (size_t)c * n;
+                for (uint32_t r = 0; r < rows_now; r++) {
+                    SHP_REQUIRE(!src[r].geq_p(), SHP_ERR_FORMAT, "prove_assigned: advice value is not a canonical field element");
+                    dst[r] = src[r];
+                }
+            }
+            pr->grid_foreign = true;
+            instances.assign(in.instances, in.instances + in.n_instances);
+            for (auto& v : instances) SHP_REQUIRE(!v.geq_p(), SHP_ERR_FORMAT, "prove_assigned: public input is not a canonical field element");
+        } else {
+            std::vector<Fr> inputs(n_inputs);
+            for (size_t i = 0; i < n_inputs; i++) {
+                Fr raw;
+                memcpy(raw.l, inputs_le32 + 32 * i, 32);
+                SHP_REQUIRE(!raw.geq_p(), SHP_ERR_FORMAT, "prove: witness input is not a canonical field element");
+                inputs[i] = Fr::from_raw(raw);
+            }
+            if (pr->grid_foreign) {                         // an assigned-columns proof left other cells behind
+                memset(grid, 0, (size_t)A * n * sizeof(Fr));
+                pr->grid_foreign = false;
+            }
+            // no per-proof clearing: the program writes the same cells every time (fixed plan), the blinding rows are
+            // redrawn below, everything else has been zero since prover_create
+            if (pr->wworkers) pr->wworkers->run(P, inputs, grid, pr->wsched);
+            else run_witness_range(P, inputs, grid, pr->wscratch.data(), 0, (uint32_t)P.wops.size());
+            instances.resize(P.instance_map.size());
+            for (size_t i = 0; i < instances.size(); i++)
+                instances[i] = grid[(size_t)P.instance_map[i].first * n + P.instance_map[i].second];
+            rows_now = P.adv_rows;
+        }
+        pc.mark("run_witness");
+        for (uint32_t c = 0; c < A; c++)
+            for (uint32_t r = u; r < n; r++) grid[(size_t)c * n + r] = draw();
+        pc.mark("blind_draws");
+        ctr += A;                                           // one (unused) commitment blind per advice column
+        for (size_t i = 0; i < instances.size(); i++) instcol[i] = instances[i];
+        // only the rows this proof assigns and the blinding rows travel; the rest is zero on both sides
+        if (A && rows_now < pr->dev_rows)                   // the previous proof filled more rows than this one
+            hipLaunchKernelGGL(zero_rows_kernel, dim3(ceil_div(pr->dev_rows - rows_now, 256), A), dim3(256), 0, st, V(0), (size_t)n,
+                               rows_now, pr->dev_rows);
+        pr->dev_rows = rows_now;
+        for (auto& v : instances) tr.common_scalar(v);
+        pc.mark("witness+upload");
+        // ---- P2: advice commitments.  The random polynomial of P7 depends on no challenge: its
+        // coefficients (blinding stream position known up front) and its commitment ride in the same launch.
+        const MsmRows adv_rows{rows_now, u, n - u};       // assigned rows + blinding rows; the rest is zero
+        if (split_commits) {
+            // witness rows and instances in one dispatch; the random polynomial is on its way already
+            ingest(0, A + 1, rows_now, (uint32_t)instances.size());
+            commit_launch(pr->msm_ws, srs->msm_gl, V(0), A, pts.data(), &adv_rows);
+            msm_finish_jobs(pr->msm_ws_rand, st);
+            msm_finish_jobs(pr->msm_ws, st);
+        } else {
+            // witness rows, instances and the random polynomial reach the device in one dispatch (ingest_kernel), and the random
+            // polynomial's commitment rides in the advice columns' launch
+            ingest(0, A + 2, rows_now, (uint32_t)instances.size());
+            commit(srs->msm_gl, V(0), A, pts.data(), &adv_rows, srs->msm_g, pr->rand_poly, 1);
+            rand_comm = pts[A];
+        }
+        for (uint32_t c = 0; c < A; c++) tr.write_point(pts[c].x, pts[c].y);
+    } else {
+        // Several phases (halo2 create_proof's loop over the phases; the reference's verifier reads the proof this way,
+        // /root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:267-282): per phase the witness with the challenges
+        // known so far, blinding rows and commitments of this phase's columns, then the challenges usable after it.  No
+        // overlap of the commitments with later work here: a phase's witness needs the challenges the commitments produce.
+        std::vector<Fr> inputs;
+        if (!assigned) {
+            inputs.resize(n_inputs);
+            for (size_t i = 0; i < n_inputs; i++) {
+                Fr raw;
+                memcpy(raw.l, inputs_le32 + 32 * i, 32);
+                SHP_REQUIRE(!raw.geq_p(), SHP_ERR_FORMAT, "prove: witness input is not a canonical field element");
+                inputs[i] = Fr::from_raw(raw);
+            }
+            if (pr->grid_foreign) {
+                memset(grid, 0, (size_t)A * n * sizeof(Fr));
+                pr->grid_foreign = false;
+            }
+            rows_now = P.adv_rows;
+        } else {
+            rows_now = in.assigned_rows ? in.assigned_rows : u;
+            pr->grid_foreign = true;
+        }
+        const MsmRows adv_rows{rows_now, u, n - u};
+        for (uint32_t ph = 0; ph < P.num_phases; ph++) {
+            const auto runs = P.phase_runs(ph);
+            if (assigned) {
+                const Fr* src_all = in.advice;
+                if (in.phase_fn) {
+                    src_all = (const Fr*)in.phase_fn(in.phase_user, ph, (const uint64_t*)chal.data(), chal.size());
+                    SHP_REQUIRE(src_all, SHP_ERR_INVALID_ARG, "prove_assigned: the phase callback returned no columns");
+                }
+                for (const auto& run : runs)
+                    for (uint32_t c = run.first; c < run.first + run.second; c++) {
+                        const Fr* src = src_all + (size_t)c * n;
+                        Fr* dst = grid + (size_t)c * n;
+                        for (uint32_t r = 0; r < rows_now; r++) {
+                            SHP_REQUIRE(!src[r].geq_p(), SHP_ERR_FORMAT, "prove_assigned: advice value is not a canonical field element");
+                            dst[r] = src[r];
+                        }
+                    }
+                if (ph == 0) {
+                    instances.assign(in.instances, in.instances + in.n_instances);
+                    for (auto& v : instances)
+                        SHP_REQUIRE(!v.geq_p(), SHP_ERR_FORMAT, "prove_assigned: public input is not a canonical field element");
+                }
+            } else {
+                run_witness_range(P, inputs, grid, pr->wscratch.data(), P.wops_begin(ph), P.wops_end[ph], chal.data());
+                if (ph == 0) {
+                    instances.resize(P.instance_map.size());
+                    for (size_t i = 0; i < instances.size(); i++)
+                        instances[i] = grid[(size_t)P.instance_map[i].first * n + P.instance_map[i].second];
+                }
+            }
+            // blinding rows of this phase's columns, then one (unused) commitment blind per column
+            uint32_t cols = 0;
+            for (const auto& run : runs)
+                for (uint32_t c = run.first; c < run.first + run.second; c++, cols++)
+                    for (uint32_t r = u; r < n; r++) grid[(size_t)c * n + r] = draw();
+            ctr += cols;
+            if (ph == 0) {
+                for (size_t i = 0; i < instances.size(); i++) instcol[i] = instances[i];
+                if (A && rows_now < pr->dev_rows)
+                    hipLaunchKernelGGL(zero_rows_kernel, dim3(ceil_div(pr->dev_rows - rows_now, 256), A), dim3(256), 0, st, V(0),
+                                       (size_t)n, rows_now, pr->dev_rows);
+                pr->dev_rows = rows_now;
+                for (auto& v : instances) tr.common_scalar(v);
+                // the instance column (and, unless it is on its way already, the random polynomial)
+                ingest(A, split_commits ? 1 : 2, rows_now, (uint32_t)instances.size());
+            }
+            for (const auto& run : runs) ingest(run.first, run.second, rows_now, 0);
+            for (const auto& run : runs) {
+                MsmJob job{srs->msm_gl, V(run.first), n, run.second, adv_rows, pts.data() + run.first};
+                if (!srs->msm_gl->direct) msm_run_ws(srs->msm_gl, pr->msm_ws, V(run.first), n, n, run.second, pts.data() + run.first, st);
+                else if (pr->comb) pr->comb->run(&job, 1, st, pr->comb_event);
+                else msm_run_jobs(&job, 1, pr->msm_ws, st);
+            }
+            if (ph == 0 && !split_commits) commit(srs->msm_g, pr->rand_poly, 1, &rand_comm);
+            for (const auto& run : runs)
+                for (uint32_t c = run.first; c < run.first + run.second; c++) tr.write_point(pts[c].x, pts[c].y);
+            for (size_t i = 0; i < chal.size(); i++)
+                if (P.challenge_phase[i] == ph) chal[i] = tr.squeeze();
+        }
+        if (split_commits) msm_finish_jobs(pr->msm_ws_rand, st);
+        pc.mark("advice_phases");
+    }
     const Fr theta = tr.squeeze();
 
     ProgArgs pa;
     pa.out_raw = nullptr;
     pa.consts = pk->consts;
+    if (phased) {                                       // every challenge is known: they complete the lane's constant table
+        h2d(pr->consts_lane + P.consts.size(), chal.data(), chal.size() * sizeof(Fr));
+        pa.consts = pr->consts_lane;
+    }
     pa.adv_q = pk->adv_q; pa.fix_q = pk->fix_q; pa.inst_q = pk->inst_q;
     auto lagrange_domain = [&](ProgArgs& a) {
         a.adv_base = V(0); a.adv_stride = n;
@@ -1782,6 +1905,21 @@ int32_t shp_pk_info(const shp_pk* pk, uint32_t* k, uint32_t* n_witness_inputs, u
     });
 }
 
+int32_t shp_pk_phases(const shp_pk* pk, uint32_t* num_phases, uint32_t* num_challenges, uint32_t* num_advice,
+                      uint32_t* advice_phase, size_t advice_cap) {
+    return guarded([&] {
+        SHP_REQUIRE(pk, SHP_ERR_INVALID_ARG, "pk_phases: null pk");
+        const PlanData& P = pk->plan;
+        if (num_advice) *num_advice = P.num_advice;
+        if (num_phases) *num_phases = P.num_phases;
+        if (num_challenges) *num_challenges = (uint32_t)P.challenge_phase.size();
+        if (advice_phase) {
+            SHP_REQUIRE(advice_cap >= P.num_advice, SHP_ERR_INVALID_ARG, "pk_phases: one entry per advice column is written");
+            for (uint32_t c = 0; c < P.num_advice; c++) advice_phase[c] = P.advice_phase[c];
+        }
+    });
+}
+
 int32_t shp_pk_gate_compiled(const shp_pk* pk, int32_t* compiled) {
     return guarded([&] {
         SHP_REQUIRE(pk && compiled, SHP_ERR_INVALID_ARG, "pk_gate_compiled: null argument");
@@ -1826,7 +1964,7 @@ int32_t shp_public_inputs(const shp_pk* pk, const uint8_t* witness_le32, size_t 
         }
         // the witness program on the host, no GPU work: only the cells the public inputs are read from matter
         std::vector<Fr> grid((size_t)P.num_advice * P.n, Fr::zero()), scratch(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
-        run_witness_range(P, inputs, grid.data(), scratch.data(), 0, (uint32_t)P.wops.size());
+        run_witness_range(P, inputs, grid.data(), scratch.data(), 0, P.wops_end[0]);   // public inputs are first-phase cells
         for (size_t i = 0; i < P.instance_map.size(); i++) {
             Fr raw = grid[(size_t)P.instance_map[i].first * P.n + P.instance_map[i].second].to_raw();
             memcpy(instances_le32 + 32 * i, raw.l, 32);
@@ -1955,6 +2093,30 @@ int32_t shp_prove_assigned(shp_prover* p, const uint64_t* advice, size_t n_colum
         std::vector<Fr> inst;
         ProveInput in;
         in.advice = reinterpret_cast<const Fr*>(advice);
+        in.assigned_rows = (uint32_t)assigned_rows;
+        in.instances = reinterpret_cast<const Fr*>(instances);
+        in.n_instances = n_instances;
+        if (randomness) { in.draws = reinterpret_cast<const Fr*>(randomness); in.n_draws = n_draws; }
+        else in.seed = seed;
+        prove_impl(p, in, proof, inst);
+        proof_out_copy(proof, inst, proof_out, proof_cap, proof_len, nullptr, 0);
+    });
+}
+
+int32_t shp_prove_assigned_phased(shp_prover* p, shp_phase_fn synthesize, void* user, size_t n_columns, size_t n_rows,
+                                  size_t assigned_rows, const uint64_t* instances, size_t n_instances, const uint64_t* randomness,
+                                  size_t n_draws, const uint8_t* seed, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+    return guarded([&] {
+        SHP_REQUIRE(p && synthesize && proof_out && proof_len, SHP_ERR_INVALID_ARG, "prove_assigned_phased: null argument");
+        const PlanData& P = p->pk->plan;
+        SHP_REQUIRE(n_columns == P.num_advice && n_rows == P.n, SHP_ERR_INVALID_ARG,
+                    "prove_assigned_phased: the advice block must be num_advice columns of 2^k rows");
+        SHP_REQUIRE(assigned_rows <= P.usable, SHP_ERR_INVALID_ARG, "prove_assigned_phased: more assigned rows than usable rows");
+        std::vector<uint8_t> proof;
+        std::vector<Fr> inst;
+        ProveInput in;
+        in.phase_fn = synthesize;
+        in.phase_user = user;
         in.assigned_rows = (uint32_t)assigned_rows;
         in.instances = reinterpret_cast<const Fr*>(instances);
         in.n_instances = n_instances;

@@ -408,12 +408,13 @@ bool read_scalar(const uint8_t* b, Fr& out) {
 
 // the plan's expression programs over scalars (the verifier evaluates them at the claimed openings)
 template <class FA, class FF, class FI>
-std::vector<Fr> run_program_scalar(const std::vector<Instr>& prog, uint32_t nslots, const std::vector<Fr>& consts, FA adv, FF fix,
-                                   FI inst) {
+std::vector<Fr> run_program_scalar(const std::vector<Instr>& prog, uint32_t nslots, const std::vector<Fr>& consts,
+                                   const std::vector<Fr>& chal, FA adv, FF fix, FI inst) {
     std::vector<Fr> slots(nslots, Fr::zero()), outs;
     for (const Instr& in : prog) {
         switch (in.op) {
             case OP_CONST: slots[in.dst] = consts[in.a]; break;
+            case OP_CHAL: slots[in.dst] = chal[in.a]; break;
             case OP_ADV: slots[in.dst] = adv(in.a); break;
             case OP_FIX: slots[in.dst] = fix(in.a); break;
             case OP_INST: slots[in.dst] = inst(in.a); break;
@@ -468,8 +469,18 @@ static bool verify_impl(const VkView& vk, const uint8_t* proof, size_t proof_len
         pos += 64;
         return p;
     };
+    // advice commitments phase by phase, the challenges usable after a phase squeezed behind its commitments
+    // (Halo2Verifier.sol:267-282; a single-phase circuit: all columns, no challenge)
     std::vector<G1Affine> adv_c(A);
-    for (auto& p : adv_c) p = rd_point();
+    std::vector<Fr> chal(P.challenge_phase.size(), Fr::zero());
+    for (uint32_t ph = 0; ph < P.num_phases; ph++) {
+        for (uint32_t c = 0; c < A; c++)
+            if (P.advice_phase[c] == ph) adv_c[c] = rd_point();
+        for (size_t i = 0; i < chal.size(); i++)
+            if (P.challenge_phase[i] == ph) chal[i] = tr.squeeze();
+    }
+    if (trace)
+        for (size_t i = 0; i < chal.size() && 32 * (22 + i + 1) <= trace->size(); i++) tput_fr(22 + i, chal[i]);
     const Fr theta = tr.squeeze();
     std::vector<G1Affine> lpi_c(L), lpt_c(L);
     for (uint32_t l = 0; l < L; l++) { lpi_c[l] = rd_point(); lpt_c[l] = rd_point(); }
@@ -533,7 +544,7 @@ static bool verify_impl(const VkView& vk, const uint8_t* proof, size_t proof_len
     auto fixq = [&](uint32_t q) { return ev.at({5, P.fix_q[q].col, P.fix_q[q].rot}); };
     auto instq = [&](uint32_t) { return inst_eval; };
     Fr numer = Fr::zero();
-    for (const Fr& e : run_program_scalar(P.gate_prog, P.gate_slots, P.consts, advq, fixq, instq)) numer = numer * y + e;
+    for (const Fr& e : run_program_scalar(P.gate_prog, P.gate_slots, P.consts, chal, advq, fixq, instq)) numer = numer * y + e;
     auto col_eval = [&](uint32_t t, uint32_t i) { return t == COL_ADVICE ? ev.at({0, i, 0}) : t == COL_FIXED ? ev.at({5, i, 0}) : inst_eval; };
     if (S) {
         const Fr z0 = ev.at({1, 0, 0});
@@ -558,7 +569,7 @@ static bool verify_impl(const VkView& vk, const uint8_t* proof, size_t proof_len
         auto comp = [&](const std::vector<Instr>& prog, uint32_t ns) {
             Fr acc = Fr::zero();
             bool first = true;
-            for (const Fr& e : run_program_scalar(prog, ns, P.consts, advq, fixq, instq)) {
+            for (const Fr& e : run_program_scalar(prog, ns, P.consts, chal, advq, fixq, instq)) {
                 acc = first ? e : acc * theta + e;
                 first = false;
             }
@@ -701,7 +712,9 @@ extern "C" int32_t shp_verify_trace(const shp_pk* pk, const uint8_t* proof, size
         SHP_REQUIRE(words_cap >= 22 * 32, SHP_ERR_INVALID_ARG, "verify_trace: 22 words of 32 bytes are written");
         VkView vk;
         shp_pk_vk_view(pk, vk);
-        std::vector<uint8_t> tr(22 * 32, 0);
+        // a circuit with several phases: its challenges follow the 22 words when the buffer has room for all of them
+        const size_t nch = vk.plan->challenge_phase.size();
+        std::vector<uint8_t> tr((22 + (words_cap >= (22 + nch) * 32 ? nch : 0)) * 32, 0);
         *accepted = verify_impl(vk, proof, proof_len, instances_le32, n_instances, &tr) ? 1 : 0;
         memcpy(words_be32, tr.data(), tr.size());
     });
