@@ -86,7 +86,7 @@ def main():
     assert a.pools == 1 or a.native, "--pools needs --native"
     assert not a.http or a.native, "--http needs --native"
     if a.pools > 1:
-        os.environ.setdefault("SHP_MSM_TABLE_GB", str(200 // (2 * a.pools)))     # every pool's SRS builds its own tables on the one GPU
+        os.environ.setdefault("SHP_MSM_TABLE_GB", str(160 // a.pools))     # every pool's SRS builds its own table on the one GPU
     ctxs, keys, pools = [], [], []
     for _ in range(a.pools):
         ctx = shp.Context(0)

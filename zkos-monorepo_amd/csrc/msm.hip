@@ -988,16 +988,16 @@ static uint32_t pick_window(size_t n) {
 }
 
 // Direct-table budget per plan (GiB); SHP_MSM_TABLE_GB=0 forces the bucket method.
-// An SRS holds two bases.  The Lagrange basis carries two thirds of a proof's commitments (advice, permuted lookup
-// columns, grand products, the SHPLONK quotients), so it is the PRIMARY table: built first, it may take c = 15 (k = 13:
-// 146 GB, 17 windows).  The coefficient basis (random polynomial, quotient pieces) and every stand-alone plan stop at
-// c = 14 (82 GB, 19 windows; c = 13: 43 GB, 20 windows, -1.5 % proofs/s; c = 12: -5 %).
+// An SRS holds two bases.  The Lagrange basis carries EVERY commitment of a proof (the prover transforms the random
+// polynomial and the quotient pieces to their values on the domain and commits to those), so it is the PRIMARY table:
+// built first, it may take c = 15 (k = 13: 146 GB, 17 windows).  The coefficient basis serves shp_srs_commit callers
+// only and gets a small table (8 GiB: c = 10 at k = 13); a stand-alone plan stops at c = 14.
 enum class TableRole { Single, Primary, Secondary };
 
 static double direct_budget_gib(TableRole role) {
     const char* e = getenv("SHP_MSM_TABLE_GB");
-    if (e && *e) return atof(e);
-    return role == TableRole::Primary ? 140.0 : 84.0;
+    if (e && *e) return role == TableRole::Secondary ? std::min(8.0, atof(e)) : atof(e);
+    return role == TableRole::Primary ? 140.0 : role == TableRole::Secondary ? 8.0 : 84.0;
 }
 
 // scalars are canonical (< r < 2^254)

@@ -1087,11 +1087,12 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     // next challenge is queued BEHIND the commitment kernel and runs while the host waits for the points (their stamps in
     // pinned memory, not the stream), normalises and hashes them.  Pool lanes, lanes behind a combiner and profiled lanes
     // commit in one piece.
-    const bool split_commits = pr->msm_ws.poll_results && !pr->comb && !pr->timers.enabled && srs->msm_gl->direct && srs->msm_g->direct;
+    const bool split_commits = pr->msm_ws.poll_results && !pr->comb && !pr->timers.enabled && srs->msm_gl->direct;
     // P9's transforms: coefficient form, then the nc cosets of the quotient domain, of every column.  (Cut into column
     // ranges and queued behind the earlier commitments as well -- advice columns are final after P2 -- they filled those
     // waits, but a two-pass transform launch has a floor of 20 us whatever its size: what the waits gained the smaller
     // launches lost again, measured.)
+    NttOpts ntt_fwd;
     NttOpts ntt_inv;
     ntt_inv.inverse = true;
     NttOpts ntt_ext;                                     // values on the nc cosets of the quotient domain
@@ -1131,9 +1132,15 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         }
         hipLaunchKernelGGL(ingest_kernel, dim3(ceil_div(n, 256), rows), dim3(256), 0, st, ia);
     };
+    // Every commitment of a proof goes through the LAGRANGE basis and its one multiples table: the polynomials that exist
+    // as coefficients (this one, the quotient pieces) are transformed to their values on the domain first -- the same group
+    // element, 17 windows instead of the 19 a second table of affordable size would have, and no second table (82 GB).
+    Fr* const rand_lag = pr->lag2 + n;                   // also what the evaluation-form opening reads later
+    auto rand_values = [&] { ntt_launch(ctx, pr->rand_poly, rand_lag, k, 1, ntt_fwd, st, pr->ntt_tmp); };
     if (split_commits) {
         ingest(A + 1, 1, 0, 0);
-        commit_launch(pr->msm_ws_rand, srs->msm_g, pr->rand_poly, 1, &rand_comm);
+        rand_values();
+        commit_launch(pr->msm_ws_rand, srs->msm_gl, rand_lag, 1, &rand_comm);
     }
     // ---- P0/P1: witness, blinding rows, instance column
     std::vector<Fr> instances;
@@ -1211,7 +1218,8 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             // witness rows, instances and the random polynomial reach the device in one dispatch (ingest_kernel), and the random
             // polynomial's commitment rides in the advice columns' launch
             ingest(0, A + 2, rows_now, (uint32_t)instances.size());
-            commit(srs->msm_gl, V(0), A, pts.data(), &adv_rows, srs->msm_g, pr->rand_poly, 1);
+            rand_values();
+            commit(srs->msm_gl, V(0), A, pts.data(), &adv_rows, srs->msm_gl, rand_lag, 1);
             rand_comm = pts[A];
         }
         for (uint32_t c = 0; c < A; c++) tr.write_point(pts[c].x, pts[c].y);
@@ -1292,7 +1300,10 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
                 else if (pr->comb) pr->comb->run(&job, 1, st, pr->comb_event);
                 else msm_run_jobs(&job, 1, pr->msm_ws, st);
             }
-            if (ph == 0 && !split_commits) commit(srs->msm_g, pr->rand_poly, 1, &rand_comm);
+            if (ph == 0 && !split_commits) {
+                rand_values();
+                commit(srs->msm_gl, rand_lag, 1, &rand_comm);
+            }
             for (const auto& run : runs)
                 for (uint32_t c = run.first; c < run.first + run.second; c++) tr.write_point(pts[c].x, pts[c].y);
             for (size_t i = 0; i < chal.size(); i++)
@@ -1512,7 +1523,9 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     const uint32_t npieces = P.degree - 1;
     ctr += npieces;                                      // one (unused) blind per quotient piece
     SHP_REQUIRE(ctr == randomness_len(P), SHP_ERR_INTERNAL, "prove: blinding stream length");
-    commit(srs->msm_g, hp, npieces, pts.data());
+    Fr* const hp_lag = pr->h;                            // the pieces' values on the domain (the interpolants are consumed)
+    ntt_launch(ctx, hp, hp_lag, k, npieces, ntt_fwd, st, pr->ntt_tmp);
+    commit(srs->msm_gl, hp_lag, npieces, pts.data());
     for (uint32_t i = 0; i < npieces; i++) tr.write_point(pts[i].x, pts[i].y);
     pc.mark("quotient_msm");
     // ---- P11: evaluations
@@ -1543,8 +1556,9 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
                 for (uint32_t b = 0; b < k; b++) { sq.v[p][b] = v; v = Fr::sqr(v); }
             }
         }
-        hipLaunchKernelGGL(powers_kernel, dim3(ceil_div(ceil_div(n, per), 256), (uint32_t)points.size() + 1), dim3(256), 0, st,
-                           d_points, (uint32_t)points.size(), n, per, pr->pw, (const Fr*)hp, npieces, xn, pr->hx, sq, bits);
+        hipLaunchKernelGGL(powers_kernel, dim3(ceil_div(ceil_div(n, per), 256), (uint32_t)points.size() + 2), dim3(256), 0, st,
+                           d_points, (uint32_t)points.size(), n, per, pr->pw, (const Fr*)hp, npieces, xn, pr->hx,
+                           (const Fr*)hp_lag, pr->lag2, sq, bits);
     }
     // the eval list in proof order, then h(x) (needed only for the opening argument)
     std::vector<EvalJob> jobs;
@@ -1594,9 +1608,8 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     for (size_t i = 0; poll_evals && i < jobs.size(); i++) eval_stamp[i] = eval_seq - 1;
     hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)jobs.size()), dim3(EVAL_THREADS), 0, st, pr->jobs, pr->pw, n, evals, eval_stamp,
                        eval_seq);
-    // Lagrange values of hx and the random polynomial for the evaluation-form opening
-    NttOpts fwd;
-    ntt_launch(ctx, pr->hx, pr->lag2, k, 2, fwd, st, pr->ntt_tmp);   // out of place: hx | rand_poly are adjacent
+    // (the values of hx and of the random polynomial on the domain, which the evaluation-form opening reads, exist already:
+    // lag2 from the powers launch above, rand_lag from the random polynomial's commitment)
     // 1 / (omega^r - point) for every opening point: it depends on x alone, so it is queued here, behind the evaluations,
     // and runs while the host hashes them and prepares the opening argument
     invert_point_diffs(d_points, points.data(), pr->dinv, (uint32_t)points.size());

@@ -874,21 +874,24 @@ __global__ void coset_combine_kernel(const Fr* q, const Fr* cinv, const Fr* vinv
 // ------------------------------------------------------------------ evaluations
 // pw[p][i] = point_p^i
 // the row of blockIdx.y == n_points forms hx = sum_i x^(n i) piece_i instead (Horner over the quotient pieces): the two
-// are independent and share a dispatch
+// are independent and share a dispatch; the row behind it does the same over the pieces' values on the domain
+// (pieces_lag -> hx_lag: the combination is linear, so hx needs no transform of its own)
 // sq (bits > 0): sq.v[p][b] = point_p^(2^b), b < bits, squared out by the host and passed by value: a thread's first
 // power is then the product over the set bits of its index -- at most `bits` dependent products, six or seven on
 // average, where square-and-multiply from the point itself chains `bits` squarings and as many products
 constexpr uint32_t POW_TABLE_POINTS = 8, POW_TABLE_BITS = 14;
 struct PowTable { Fr v[POW_TABLE_POINTS][POW_TABLE_BITS]; };
 __global__ void powers_kernel(const Fr* points, uint32_t n_points, uint32_t n, uint32_t per, Fr* pw, const Fr* pieces,
-                              uint32_t n_pieces, Fr xn, Fr* hx, PowTable sq, uint32_t bits) {
+                              uint32_t n_pieces, Fr xn, Fr* hx, const Fr* pieces_lag, Fr* hx_lag, PowTable sq, uint32_t bits) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t p = blockIdx.y;
-    if (p == n_points) {
+    if (p >= n_points) {
+        const Fr* src = p == n_points ? pieces : pieces_lag;
+        Fr* dst = p == n_points ? hx : hx_lag;
         for (uint32_t i = t * per; i < (t + 1) * per && i < n; i++) {
             Fr acc = Fr::zero();
-            for (int q = (int)n_pieces - 1; q >= 0; q--) acc = acc * xn + ld(pieces + (size_t)q * n + i);
-            st(hx + i, acc);
+            for (int q = (int)n_pieces - 1; q >= 0; q--) acc = acc * xn + ld(src + (size_t)q * n + i);
+            st(dst + i, acc);
         }
         return;
     }
