@@ -299,6 +299,12 @@ int32_t shp_prove_with_randomness(shp_prover* p, const uint8_t* witness_le32, si
 int32_t shp_prove_assigned(shp_prover* p, const uint64_t* advice, size_t n_columns, size_t n_rows, size_t assigned_rows,
                            const uint64_t* instances, size_t n_instances, const uint64_t* randomness, size_t n_draws,
                            const uint8_t* seed, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+/* The plan's witness program alone, on the host (no GPU): the advice columns shp_prove would commit to -- n_columns x n_rows
+ * Montgomery limbs, column-major, as shp_prove_assigned takes them (blinding rows zero) -- the public inputs (optional) and
+ * the number of leading rows the program assigns.  What a host that synthesises elsewhere would hand to
+ * shp_prove_assigned / shp_pool_submit_assigned; single-phase circuits only. */
+int32_t shp_witness_columns(const shp_pk* pk, const uint8_t* witness_le32, size_t n_inputs, uint64_t* advice, size_t n_columns,
+                            size_t n_rows, uint64_t* instances, size_t n_instances, size_t* assigned_rows);
 /* generate_proof for a circuit with SEVERAL PHASES -- advice columns assigned after challenges have been squeezed from the
  * transcript (halo2's advice_column_in(SecondPhase) / challenge_usable_after(FirstPhase)).  None of the reference's circuits
  * has a second phase, but its verifier generator supports them
@@ -407,6 +413,13 @@ int32_t shp_pool_lane(shp_pool* p, uint32_t index, shp_prover** lane);   /* e.g.
 /* asynchronous: enqueue one proof (arguments as shp_prove; the witness is copied), SHP_ERR_BUSY when
  * the queue is full; collect it with shp_pool_wait, which returns the proof's own status */
 int32_t shp_pool_submit(shp_pool* p, const uint8_t* witness_le32, size_t n_inputs, const uint8_t seed[32], uint64_t* ticket);
+/* shp_pool_submit for a circuit the CALLER synthesised (shp_prove_assigned's arguments; a seed or a randomness buffer): the
+ * way a host with the reference's real circuits -- whose `synthesize` runs in its own threads -- reaches the pool's
+ * throughput.  The job takes a copy of the rows that are read (assigned_rows per column; 0 = all usable rows), the caller's
+ * block is free on return.  shp_pool_wait hands the same public inputs back.  Not for circuits with several phases. */
+int32_t shp_pool_submit_assigned(shp_pool* p, const uint64_t* advice, size_t n_columns, size_t n_rows, size_t assigned_rows,
+                                 const uint64_t* instances, size_t n_instances, const uint64_t* randomness, size_t n_draws,
+                                 const uint8_t* seed, uint64_t* ticket);
 int32_t shp_pool_wait(shp_pool* p, uint64_t ticket, uint8_t* proof_out, size_t proof_cap, size_t* proof_len,
                       uint8_t* instances_le32, size_t instances_cap);
 /* shp_pool_wait bounded by the reference's run timeout (tokio_task_pool with_run_timeout, TEE_COMPUTE_TIMEOUT_SECS = 60,

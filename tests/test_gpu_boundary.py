@@ -99,6 +99,52 @@ def test_assigned_columns_equal_the_witness_program(shp, oracle, gpu_ctx):
     pr.close(); pk.close(); params.close()
 
 
+def test_pool_takes_the_callers_columns(shp, oracle, gpu_ctx):
+    """shp_pool_submit_assigned: jobs from caller-synthesised columns go through the pool's lanes next to witness-program
+    jobs and give the same bytes; shp_witness_columns (the witness program alone, on the host) produces exactly the
+    columns the oracle's synthesis does"""
+    PL, C, plan, lay, osrs, opk, params, pk, H = small_setup(shp, oracle, gpu_ctx)
+    wits = [C.withdraw_witness_inputs(lay, H, random.Random(70 + i), 2**31 + 9 + i, 2**20 + 1 + i) for i in range(10)]
+    seeds = [bytes([70 + i]) * 32 for i in range(10)]
+    want = [PL.prove(opk, osrs, w, s) for w, s in zip(wits, seeds)]
+    cols = [pk.witness_columns(w) for w in wits]
+    adv0, inst0 = PL.synthesize(plan, wits[0])
+    assert np.array_equal(cols[0][0], np.stack([oracle.fr_array(c) for c in adv0]))
+    assert oracle.fr_ints(cols[0][1]) == list(inst0) == want[0][1]
+    used = max(r for col in adv0 for r, v in enumerate(col) if v) + 1
+    assert used <= cols[0][2] <= plan.usable
+    pool = shp.Pool(pk, 3)
+    tickets = []
+    for i, (adv, inst, rows) in enumerate(cols):
+        if i % 3 == 2:
+            tickets.append(pool.submit(b"".join(int(x).to_bytes(32, "little") for x in wits[i]), seeds[i]))
+        else:
+            tickets.append(pool.submit_assigned(adv, inst, assigned_rows=rows if i % 2 else 0, seed=seeds[i]))
+    for i, t in enumerate(tickets):
+        assert pool.wait(t) == want[i], f"job {i}"
+    draws = shp.blinding_stream(bytes([3]) * 32, 0, pk.n_draws)
+    t = pool.submit_assigned(cols[1][0], cols[1][1], assigned_rows=cols[1][2], draws=draws)
+    assert pool.wait(t)[0] == PL.prove(opk, osrs, wits[1], None, randomness=draws)[0]
+    for bad in (lambda: pool.submit_assigned(cols[0][0][:-1], cols[0][1], seed=seeds[0]),
+                lambda: pool.submit_assigned(cols[0][0], cols[0][1][:-1], seed=seeds[0]),
+                lambda: pool.submit_assigned(cols[0][0], cols[0][1], assigned_rows=plan.usable + 1, seed=seeds[0]),
+                lambda: pool.submit_assigned(cols[0][0], cols[0][1]),
+                lambda: pool.submit_assigned(cols[0][0], cols[0][1], draws=draws[:-1])):
+        with pytest.raises(shp.ShpError) as e:
+            bad()
+        assert e.value.code == shp.SHP_ERR_INVALID_ARG
+    # a column value that is no field element fails that job, not the pool
+    broken = cols[2][0].copy()
+    broken[1, 5] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    t = pool.submit_assigned(broken, cols[2][1], seed=seeds[2])
+    with pytest.raises(shp.ShpError) as e:
+        pool.wait(t)
+    assert e.value.code == shp.SHP_ERR_FORMAT
+    t = pool.submit_assigned(cols[2][0], cols[2][1], seed=seeds[2])
+    assert pool.wait(t) == want[2]
+    pool.close(); pk.close(); params.close()
+
+
 def test_injected_transcript_repr(shp, oracle, gpu_ctx):
     """the first absorbed word is the caller's vk.transcript_repr(): proof == the oracle's with the same word, the native
     verifier accepts it, a key without it rejects it, and the saved key keeps it"""

@@ -431,6 +431,19 @@ class ProvingKey:
         _check(lib().shp_pk_plan(self.h, out, C.c_size_t(n.value), C.byref(n)))
         return out.raw[:n.value]
 
+    def witness_columns(self, witness_ints):
+        """shp_witness_columns: the plan's witness program alone, on the host -> (advice (A, n, 4) uint64 Montgomery limbs,
+        instances (n_instances, 4), leading rows the program assigns): what shp_prove_assigned takes"""
+        wit = b"".join(int(x).to_bytes(32, "little") for x in witness_ints)
+        A, n = len(self.phases()[2]), 1 << self.k
+        adv = np.zeros((A, n, 4), dtype=np.uint64)
+        ins = np.zeros((max(self.n_instances, 1), 4), dtype=np.uint64)
+        rows = C.c_size_t()
+        _check(lib().shp_witness_columns(self.h, C.c_char_p(wit), C.c_size_t(len(witness_ints)), adv.ctypes.data_as(C.c_void_p),
+                                         C.c_size_t(A), C.c_size_t(n), ins.ctypes.data_as(C.c_void_p), C.c_size_t(self.n_instances),
+                                         C.byref(rows)))
+        return adv, ins[:self.n_instances], rows.value
+
     def save(self) -> bytes:
         """marshall_pk: plan + verifying-key material (the rest is rebuilt on the GPU at load time)"""
         n = C.c_size_t()
@@ -705,6 +718,19 @@ class Pool:
         _check(lib().shp_pool_lane(self.h, C.c_uint32(i), C.byref(pr.h)))
         pr.close = lambda: None
         return pr
+
+    def submit_assigned(self, advice, instances, assigned_rows=0, seed: bytes = None, draws=None) -> int:
+        """shp_pool_submit_assigned: a job from caller-synthesised columns (the arguments of Prover.prove_assigned)"""
+        adv = np.ascontiguousarray(advice, dtype=np.uint64)
+        ins = np.ascontiguousarray(instances, dtype=np.uint64).reshape(-1, 4)
+        d = None if draws is None else np.ascontiguousarray(draws, dtype=np.uint64)
+        t = C.c_uint64()
+        _check(lib().shp_pool_submit_assigned(self.h, adv.ctypes.data_as(C.c_void_p), C.c_size_t(adv.shape[0]), C.c_size_t(adv.shape[1]),
+                                              C.c_size_t(assigned_rows), ins.ctypes.data_as(C.c_void_p), C.c_size_t(ins.shape[0]),
+                                              d.ctypes.data_as(C.c_void_p) if d is not None else None,
+                                              C.c_size_t(d.shape[0] if d is not None else 0),
+                                              C.c_char_p(seed) if seed is not None else None, C.byref(t)))
+        return t.value
 
     def submit(self, wit: bytes, seed: bytes) -> int:
         t = C.c_uint64()

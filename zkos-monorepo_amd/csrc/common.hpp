@@ -159,3 +159,7 @@ int shp_pk_device(const shp_pk* pk);
 // internal (not part of the C ABI): commitments of this lane go through the pool's combiner; `profile_owner` lanes
 // report the combiner's kernel timers with their own (shp_prover_profile_read)
 void shp_prover_attach_combiner(shp_prover* p, shp::MsmCombiner* c, bool profile_owner);
+int32_t shp_prove_assigned_rows(shp_prover* p, const uint64_t* advice, size_t n_columns, size_t rows, const uint64_t* instances,
+                                size_t n_instances, const uint64_t* randomness, size_t n_draws, const uint8_t* seed,
+                                uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+void shp_pk_shape(const shp_pk* pk, uint32_t* num_advice, uint32_t* n, uint32_t* usable, bool* phased, uint64_t* n_draws);

@@ -25,6 +25,11 @@ struct Job {
     std::vector<uint8_t> witness;
     uint8_t seed[32];
     size_t n_inputs = 0;
+    // a job whose columns the caller synthesised (shp_pool_submit_assigned): [num_advice][rows] Montgomery limbs, the public
+    // inputs, optionally the pre-drawn randomness instead of the seed
+    bool assigned = false;
+    size_t rows = 0;
+    std::vector<uint64_t> advice, inst_mont, draws;
     // result
     bool done = false;
     bool abandoned = false;      // its waiter gave up (shp_pool_wait_for timed out): a lane that has not started it skips it
@@ -39,6 +44,9 @@ struct shp_pool {
     shp_pk* pk = nullptr;
     int device = 0;
     uint32_t proof_len = 0, n_inputs = 0, n_instances = 0;
+    uint32_t num_advice = 0, n_rows = 0, usable = 0;
+    bool phased = false;
+    uint64_t n_draws = 0;
     size_t queue_cap = 0;
     std::vector<shp_prover*> lanes;
     std::vector<std::thread> workers;
@@ -71,8 +79,18 @@ struct shp_pool {
             j->proof.resize(proof_len);
             j->instances.resize((size_t)n_instances * 32);
             size_t len = 0;
-            int32_t rc = shp_prove(lane, j->witness.data(), j->n_inputs, j->seed, j->proof.data(), j->proof.size(), &len,
-                                   j->instances.data(), j->instances.size());
+            int32_t rc;
+            if (j->assigned) {
+                rc = shp_prove_assigned_rows(lane, j->advice.data(), num_advice, j->rows, j->inst_mont.data(), n_instances,
+                                             j->draws.empty() ? nullptr : j->draws.data(), j->draws.size() / 4, j->seed,
+                                             j->proof.data(), j->proof.size(), &len);
+                for (uint32_t i = 0; rc == SHP_OK && i < n_instances; i++)     // handed back as every other job's are
+                    rc = shp_fr_to_le32(j->inst_mont.data() + 4 * i, j->instances.data() + 32 * i);
+                std::vector<uint64_t>().swap(j->advice);                        // 0.3 - 2.6 MB per job: not kept until the wait
+            } else {
+                rc = shp_prove(lane, j->witness.data(), j->n_inputs, j->seed, j->proof.data(), j->proof.size(), &len,
+                               j->instances.data(), j->instances.size());
+            }
             std::string err = rc == SHP_OK ? std::string() : std::string(shp_last_error());
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -101,6 +119,7 @@ int32_t shp_pool_create(shp_pk* pk, uint32_t lanes, uint32_t queue_cap, shp_pool
         uint32_t k = 0;
         int32_t rc = shp_pk_info(pk, &k, &p->n_inputs, &p->n_instances, &p->proof_len);
         SHP_REQUIRE(rc == SHP_OK, rc, "pool_create: pk_info failed");
+        shp_pk_shape(pk, &p->num_advice, &p->n_rows, &p->usable, &p->phased, &p->n_draws);
         p->queue_cap = queue_cap ? queue_cap : 100;      // the reference's task-pool bound
         // pools above this many lanes schedule them for throughput (SHP_POOL_THROUGHPUT_ABOVE, default 8: measured on the
         // serve path, latency-mode lanes win up to 8 lanes -- 6 lanes 1013 vs 934 proofs/s, 8 lanes 1134 vs 1101 -- draw
@@ -177,6 +196,42 @@ int32_t shp_pool_submit(shp_pool* p, const uint8_t* witness_le32, size_t n_input
             std::lock_guard<std::mutex> lk(p->mu);
             SHP_REQUIRE(!p->stopping, SHP_ERR_INVALID_ARG, "pool_submit: pool is shutting down");
             SHP_REQUIRE(p->queue.size() < p->queue_cap, SHP_ERR_BUSY, "pool_submit: queue full");
+            j->ticket = p->next_ticket++;
+            p->queue.push_back(j);
+            p->jobs[j->ticket] = j;
+            p->outstanding++;
+            *ticket = j->ticket;
+        }
+        p->cv_work.notify_one();
+    });
+}
+
+int32_t shp_pool_submit_assigned(shp_pool* p, const uint64_t* advice, size_t n_columns, size_t n_rows, size_t assigned_rows,
+                                 const uint64_t* instances, size_t n_instances, const uint64_t* randomness, size_t n_draws,
+                                 const uint8_t* seed, uint64_t* ticket) {
+    return shp::guarded([&] {
+        SHP_REQUIRE(p && advice && ticket && (instances || !n_instances), SHP_ERR_INVALID_ARG, "pool_submit_assigned: null argument");
+        SHP_REQUIRE(!p->phased, SHP_ERR_INVALID_ARG,
+                    "pool_submit_assigned: a circuit with several phases is synthesised phase by phase (shp_prove_assigned_phased)");
+        SHP_REQUIRE(n_columns == p->num_advice && n_rows == p->n_rows && n_instances == p->n_instances, SHP_ERR_INVALID_ARG,
+                    "pool_submit_assigned: the advice block must be num_advice columns of 2^k rows, with the circuit's public inputs");
+        SHP_REQUIRE(assigned_rows <= p->usable, SHP_ERR_INVALID_ARG, "pool_submit_assigned: more assigned rows than usable rows");
+        SHP_REQUIRE((randomness != nullptr) != (seed != nullptr), SHP_ERR_INVALID_ARG, "pool_submit_assigned: pass a seed or a randomness buffer");
+        SHP_REQUIRE(!randomness || n_draws == p->n_draws, SHP_ERR_INVALID_ARG, "pool_submit_assigned: randomness buffer of the wrong length");
+        auto j = std::make_shared<Job>();
+        j->assigned = true;
+        j->rows = assigned_rows ? assigned_rows : p->usable;
+        // the job owns a compact copy (the rows that are read, column after column): the caller's block is free on return
+        j->advice.resize((size_t)n_columns * j->rows * 4);
+        for (size_t c = 0; c < n_columns; c++)
+            memcpy(j->advice.data() + c * j->rows * 4, advice + c * n_rows * 4, j->rows * 32);
+        j->inst_mont.assign(instances, instances + n_instances * 4);
+        if (randomness) j->draws.assign(randomness, randomness + n_draws * 4);
+        else memcpy(j->seed, seed, 32);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            SHP_REQUIRE(!p->stopping, SHP_ERR_INVALID_ARG, "pool_submit_assigned: pool is shutting down");
+            SHP_REQUIRE(p->queue.size() < p->queue_cap, SHP_ERR_BUSY, "pool_submit_assigned: queue full");
             j->ticket = p->next_ticket++;
             p->queue.push_back(j);
             p->jobs[j->ticket] = j;

@@ -929,7 +929,8 @@ struct PhaseClock {
 struct ProveInput {
     const uint8_t* inputs_le32 = nullptr;    // witness program: n_inputs x 32 bytes
     size_t n_inputs = 0;
-    const Fr* advice = nullptr;              // assigned columns: [A][n] Montgomery, host memory
+    const Fr* advice = nullptr;              // assigned columns: [A][advice_stride] Montgomery, host memory
+    size_t advice_stride = 0;                //   elements between columns (0: n)
     uint32_t assigned_rows = 0;              //   rows [assigned_rows, usable) of every column are zero and not read
     const Fr* instances = nullptr;           //   public inputs, Montgomery
     size_t n_instances = 0;
@@ -970,6 +971,8 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
                 "prove_assigned: a circuit with several phases is synthesised phase by phase (shp_prove_assigned_phased)");
     if (assigned) {
         SHP_REQUIRE(in.assigned_rows <= u, SHP_ERR_INVALID_ARG, "prove_assigned: more assigned rows than usable rows");
+        SHP_REQUIRE(!in.advice_stride || (in.assigned_rows && in.advice_stride >= in.assigned_rows && !in.phase_fn), SHP_ERR_INVALID_ARG,
+                    "prove_assigned: compact columns hold exactly their assigned rows");
         SHP_REQUIRE(in.n_instances == P.num_instance && (in.instances || !in.n_instances), SHP_ERR_INVALID_ARG,
                     "prove_assigned: wrong number of public inputs");
     } else {
@@ -1161,7 +1164,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             // serialise the streams of concurrent lanes), values validated on the way
             rows_now = in.assigned_rows ? in.assigned_rows : u;
             for (uint32_t c = 0; c < A; c++) {
-                const Fr* src = advice_once + (size_t)c * n;
+                const Fr* src = advice_once + (size_t)c * (in.advice_stride ? in.advice_stride : n);
                 Fr* dst = grid + (size_t)c * n;
                 for (uint32_t r = 0; r < rows_now; r++) {
                     SHP_REQUIRE(!src[r].geq_p(), SHP_ERR_FORMAT, "prove_assigned: advice value is not a canonical field element");
@@ -1718,6 +1721,11 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
 
 int shp_pk_device(const shp_pk* pk) { return pk->ctx->device; }
 
+void shp_pk_shape(const shp_pk* pk, uint32_t* num_advice, uint32_t* n, uint32_t* usable, bool* phased, uint64_t* n_draws) {
+    const PlanData& P = pk->plan;
+    *num_advice = P.num_advice; *n = P.n; *usable = P.usable; *phased = P.phased(); *n_draws = randomness_len(P);
+}
+
 void shp_pk_vk_view(const shp_pk* pk, VkView& out) {
     out.plan = &pk->plan;
     out.vk_digest = pk->vk_digest;
@@ -1985,6 +1993,34 @@ int32_t shp_public_inputs(const shp_pk* pk, const uint8_t* witness_le32, size_t 
     });
 }
 
+int32_t shp_witness_columns(const shp_pk* pk, const uint8_t* witness_le32, size_t n_inputs, uint64_t* advice, size_t n_columns,
+                            size_t n_rows, uint64_t* instances, size_t n_instances, size_t* assigned_rows) {
+    return guarded([&] {
+        SHP_REQUIRE(pk && witness_le32 && advice, SHP_ERR_INVALID_ARG, "witness_columns: null argument");
+        const PlanData& P = pk->plan;
+        SHP_REQUIRE(!P.phased(), SHP_ERR_INVALID_ARG, "witness_columns: the columns of a circuit with several phases depend on the proof's challenges");
+        SHP_REQUIRE(n_inputs == P.n_winputs, SHP_ERR_INVALID_ARG, "witness_columns: wrong number of witness inputs");
+        SHP_REQUIRE(n_columns == P.num_advice && n_rows == P.n, SHP_ERR_INVALID_ARG,
+                    "witness_columns: the advice block must be num_advice columns of 2^k rows");
+        SHP_REQUIRE(!instances || n_instances == P.num_instance, SHP_ERR_INVALID_ARG, "witness_columns: wrong number of public inputs");
+        std::vector<Fr> inputs(n_inputs);
+        for (size_t i = 0; i < n_inputs; i++) {
+            Fr raw;
+            memcpy(raw.l, witness_le32 + 32 * i, 32);
+            SHP_REQUIRE(!raw.geq_p(), SHP_ERR_FORMAT, "witness_columns: witness input is not a canonical field element");
+            inputs[i] = Fr::from_raw(raw);
+        }
+        Fr* grid = reinterpret_cast<Fr*>(advice);
+        memset(grid, 0, (size_t)P.num_advice * P.n * sizeof(Fr));
+        std::vector<Fr> scratch(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
+        run_witness_range(P, inputs, grid, scratch.data(), 0, (uint32_t)P.wops.size());
+        if (instances)
+            for (size_t i = 0; i < P.instance_map.size(); i++)
+                reinterpret_cast<Fr*>(instances)[i] = grid[(size_t)P.instance_map[i].first * P.n + P.instance_map[i].second];
+        if (assigned_rows) *assigned_rows = P.adv_rows;
+    });
+}
+
 int32_t shp_prover_witness_threads(shp_prover* p, uint32_t threads) {
     return guarded([&] {
         SHP_REQUIRE(p, SHP_ERR_INVALID_ARG, "prover_witness_threads: null prover");
@@ -2115,6 +2151,33 @@ int32_t shp_prove_assigned(shp_prover* p, const uint64_t* advice, size_t n_colum
         proof_out_copy(proof, inst, proof_out, proof_cap, proof_len, nullptr, 0);
     });
 }
+
+}  // extern "C"
+
+// a pool lane's form of shp_prove_assigned: columns that hold their first `rows` rows only, `rows` apart
+int32_t shp_prove_assigned_rows(shp_prover* p, const uint64_t* advice, size_t n_columns, size_t rows, const uint64_t* instances,
+                                size_t n_instances, const uint64_t* randomness, size_t n_draws, const uint8_t* seed,
+                                uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+    return guarded([&] {
+        SHP_REQUIRE(p && advice && proof_out && proof_len && rows, SHP_ERR_INVALID_ARG, "prove_assigned: null argument");
+        const PlanData& P = p->pk->plan;
+        SHP_REQUIRE(n_columns == P.num_advice && rows <= P.usable, SHP_ERR_INVALID_ARG, "prove_assigned: bad column block");
+        std::vector<uint8_t> proof;
+        std::vector<Fr> inst;
+        ProveInput in;
+        in.advice = reinterpret_cast<const Fr*>(advice);
+        in.advice_stride = rows;
+        in.assigned_rows = (uint32_t)rows;
+        in.instances = reinterpret_cast<const Fr*>(instances);
+        in.n_instances = n_instances;
+        if (randomness) { in.draws = reinterpret_cast<const Fr*>(randomness); in.n_draws = n_draws; }
+        else in.seed = seed;
+        prove_impl(p, in, proof, inst);
+        proof_out_copy(proof, inst, proof_out, proof_cap, proof_len, nullptr, 0);
+    });
+}
+
+extern "C" {
 
 int32_t shp_prove_assigned_phased(shp_prover* p, shp_phase_fn synthesize, void* user, size_t n_columns, size_t n_rows,
                                   size_t assigned_rows, const uint64_t* instances, size_t n_instances, const uint64_t* randomness,
