@@ -231,14 +231,14 @@ def main():
     ctx = shp.Context(local_rank % max(1, shp.device_count()))
     plan, lay = circuits.build_withdraw_plan()                 # k = 13, height 13, 12-bit range table
     # start-up cost, outside the timed region: every rank pays it (in parallel), a restarted server pays it before its
-    # first proof.  SRS = 2^13 powers of tau + the group FFT for g_lagrange + both multiples tables; key = fixed / sigma
+    # first proof.  SRS = 2^13 powers of tau + the group FFT for g_lagrange + the multiples tables; key = fixed / sigma
     # columns, their commitments and quotient-domain values; pool = lanes x (stream + 75 MB workspace)
     setup_s = {}
     t_setup = time.perf_counter()
     params = shp.Params.synthetic(ctx, 13, TAU)
     torch.cuda.synchronize()
     setup_s["srs_and_tables"] = time.perf_counter() - t_setup
-    # window width and HBM bytes of the two multiples tables the commitments gather from
+    # window width and HBM bytes of the multiples tables: every commitment of a proof gathers from the Lagrange basis's
     msm_tables = {}
     for label, basis in (("lagrange", shp.BASIS_LAGRANGE), ("monomial", shp.BASIS_MONOMIAL)):
         direct, c, nbytes = params.msm_info(basis)
