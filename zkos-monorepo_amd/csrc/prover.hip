@@ -718,8 +718,8 @@ struct shp_prover {
     EvalJob* jobs = nullptr;                                   // fixed per prover (buffer addresses, point indices): uploaded once
     bool jobs_uploaded = false;
     Fr *fsets = nullptr, *dinv = nullptr, *wvals = nullptr, *mdiff = nullptr;
-    ShplonkArgs* shp_args = nullptr;                           // one arena: the SHPLONK arguments, then the rotation
-    LincombArgs* lin = nullptr;                                // sets' combinations right behind them (one upload)
+    LincombArgs* lin = nullptr;                                // the rotation sets' polynomials: fixed per prover, uploaded once
+    bool lin_uploaded = false;
     Fr* ntt_tmp = nullptr;
     Fr* h_grid = nullptr;                                      // pinned host staging of the witness grid
     // The grid and the device columns are cleared once; the witness program rewrites the same cells every proof.  A proof
@@ -826,9 +826,7 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->dinv = pr->dalloc<Fr>((size_t)MAX_POINTS * n);
     pr->wvals = pr->dalloc<Fr>((size_t)2 * n);
     pr->mdiff = pr->dalloc<Fr>((size_t)n);                     // 1 / (omega^r - mu)
-    static_assert(sizeof(ShplonkArgs) % 8 == 0, "LincombArgs follows ShplonkArgs in one arena");
-    pr->shp_args = (ShplonkArgs*)pr->dalloc<uint8_t>(sizeof(ShplonkArgs) + MAX_SETS * sizeof(LincombArgs));
-    pr->lin = (LincombArgs*)((uint8_t*)pr->shp_args + sizeof(ShplonkArgs));
+    pr->lin = pr->dalloc<LincombArgs>(MAX_SETS);
     pr->ntt_tmp = pr->dalloc<Fr>((size_t)(NV + 1) * ne);
     pr->rank = pr->dalloc<uint32_t>((size_t)2 * L * n);
     pr->stage.reserve((size_t)1 << 20);
@@ -1639,6 +1637,16 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         }
     };
     std::vector<LincombArgs> lin(sets.size());
+    ZetaPowers zpow;
+    {
+        size_t longest = 0;
+        for (const RotSet& rs : sets) longest = std::max(longest, rs.polys.size());
+        Fr z = Fr::one();
+        for (size_t j = 0; j < MAX_SET_POLYS; j++) {
+            zpow.v[j] = j < longest ? z : Fr::zero();
+            if (j < longest) z = z * zeta_c;
+        }
+    }
     ShplonkArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.n_sets = (uint32_t)sets.size();
@@ -1653,7 +1661,6 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         Fr zp = Fr::one();
         for (size_t j = 0; j < rs.polys.size(); j++) {
             lin[i].poly[j] = values_of(rs.polys[j]);
-            lin[i].coef[j] = zp;
             for (size_t t = 0; t < rs.rots.size(); t++) comb[t] = comb[t] + zp * ev.at({rs.polys[j], rs.rots[t]});
             zp = zp * zeta_c;
         }
@@ -1669,15 +1676,13 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     }
     sa.f = pr->fsets; sa.dinv = pr->dinv; sa.omegas = pk->omegas;
     pc.mark("W_host");
-    {                                                       // both argument blocks in one upload
-        uint8_t* blk = (uint8_t*)pr->stage_alloc(sizeof(sa) + lin.size() * sizeof(LincombArgs));
-        memcpy(blk, &sa, sizeof(sa));
-        memcpy(blk + sizeof(sa), lin.data(), lin.size() * sizeof(LincombArgs));
-        SHP_HIP(hipMemcpyAsync(pr->shp_args, blk, sizeof(sa) + lin.size() * sizeof(LincombArgs), hipMemcpyHostToDevice, st));
+    if (!pr->lin_uploaded) {                                // buffer addresses: the same for every proof of this lane
+        h2d(pr->lin, lin.data(), lin.size() * sizeof(LincombArgs));
+        pr->lin_uploaded = true;
     }
-    hipLaunchKernelGGL(lincomb_kernel, dim3(ceil_div(n, 64), (uint32_t)sets.size()), dim3(pr->throughput ? 64 : 256), 0, st, pr->lin, n,
-                       pr->fsets);
-    hipLaunchKernelGGL(shplonk_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, pr->shp_args, n, pr->wvals);
+    hipLaunchKernelGGL(lincomb_kernel, dim3(ceil_div(n, 64), (uint32_t)sets.size()), dim3(pr->throughput ? 64 : 256), 0, st, pr->lin,
+                       zpow, n, pr->fsets);
+    hipLaunchKernelGGL(shplonk_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, sa, n, pr->wvals);
     commit(srs->msm_gl, pr->wvals, 1, pts.data());
     tr.write_point(pts[0].x, pts[0].y);
     pc.mark("W");

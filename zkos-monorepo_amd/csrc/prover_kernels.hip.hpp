@@ -958,22 +958,25 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_kernel(const EvalJob* jobs,
 // textbook coefficient-form division, with no polynomial division and no extra NTT.
 constexpr int MAX_SETS = 8, MAX_SET_POLYS = 96, MAX_SET_ROTS = 4, MAX_POINTS = 8;
 
+// the polynomials of a rotation set (their values on the domain): fixed per proving lane, uploaded once
 struct LincombArgs {
     const Fr* poly[MAX_SET_POLYS];
-    Fr coef[MAX_SET_POLYS];
     uint32_t count;
 };
+// zeta^j, j < the largest set: the j-th polynomial of every set is scaled by zeta^j.  Passed by value (3 KB of kernel
+// arguments) -- what changes from proof to proof reaches the kernels without an upload of its own
+struct ZetaPowers { Fr v[MAX_SET_POLYS]; };
 // grid (n / 64, sets), 64 * parts threads: wave w of a workgroup sums the polynomials j = w, w + parts, ... of its 64
 // elements and wave 0 adds the partial sums up.  A set holds up to fifty polynomials: one thread per element is a chain
 // of fifty products, which is what a lone proof waits for (parts = 4); a pool lane keeps one wave per 64 elements.
-__global__ __launch_bounds__(256) void lincomb_kernel(const LincombArgs* args, uint32_t n, Fr* out) {
+__global__ __launch_bounds__(256) void lincomb_kernel(const LincombArgs* args, ZetaPowers zp, uint32_t n, Fr* out) {
     __shared__ Fr part_sum[3][64];
     const uint32_t lane = threadIdx.x & 63, part = threadIdx.x >> 6, parts = blockDim.x >> 6;
     const uint32_t i = blockIdx.x * 64 + lane;
     const LincombArgs& a = args[blockIdx.y];
     Fr acc = Fr::zero();
     if (i < n)
-        for (uint32_t j = part; j < a.count; j += parts) acc = acc + a.coef[j] * ld(a.poly[j] + i);
+        for (uint32_t j = part; j < a.count; j += parts) acc = acc + zp.v[j] * ld(a.poly[j] + i);
     if (parts > 1) {
         if (part) part_sum[part - 1][lane] = acc;
         __syncthreads();
@@ -995,9 +998,8 @@ struct ShplonkArgs {
     const Fr* omegas;                            // omega^r
 };
 
-// W(omega^r) = sum_i nu^i (f_i - R_i)(omega^r) / Z_i(omega^r)
-__global__ void shplonk_w_kernel(const ShplonkArgs* ap, uint32_t n, Fr* out) {
-    const ShplonkArgs& a = *ap;
+// W(omega^r) = sum_i nu^i (f_i - R_i)(omega^r) / Z_i(omega^r); the arguments (1.5 KB) by value
+__global__ void shplonk_w_kernel(ShplonkArgs a, uint32_t n, Fr* out) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     Fr acc = Fr::zero();
