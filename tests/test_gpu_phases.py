@@ -112,7 +112,7 @@ def test_phased_columns_from_the_callers_own_synthesis(shp, oracle, gpu_ctx):
     pr.close(); pk.close(); params.close()
 
 
-def test_phased_key_in_a_pool_saved_and_compiled_by_the_library(shp, oracle, gpu_ctx):
+def test_phased_key_in_a_pool_saved_and_compiled_by_the_library(shp, oracle, gpu_ctx, monkeypatch):
     C = importlib.import_module("zkos-monorepo_amd.circuits")
     plan_bytes, rows = C.build_phased_plan()
     PL, plan, osrs, opk, params, pk = setup(shp, oracle, gpu_ctx, plan_bytes)
@@ -120,6 +120,14 @@ def test_phased_key_in_a_pool_saved_and_compiled_by_the_library(shp, oracle, gpu
     seeds = [bytes([20 + i]) * 32 for i in range(12)]
     want = [PL.prove(opk, osrs, w, s) for w, s in zip(wits, seeds)]
     pool = shp.Pool(pk, 3)
+    tickets = [pool.submit(b"".join(int(x).to_bytes(32, "little") for x in w), s) for w, s in zip(wits, seeds)]
+    for t, (proof, inst) in zip(tickets, want):
+        assert pool.wait(t) == (proof, inst)
+    pool.close()
+    # the same through a pool whose lanes share one commitment launch (SHP_POOL_COMBINE=1)
+    monkeypatch.setenv("SHP_POOL_COMBINE", "1")
+    pool = shp.Pool(pk, 4)
+    monkeypatch.delenv("SHP_POOL_COMBINE")
     tickets = [pool.submit(b"".join(int(x).to_bytes(32, "little") for x in w), s) for w, s in zip(wits, seeds)]
     for t, (proof, inst) in zip(tickets, want):
         assert pool.wait(t) == (proof, inst)
