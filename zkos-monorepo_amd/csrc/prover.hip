@@ -506,10 +506,12 @@ static void run_witness_range(const PlanData& P, const std::vector<Fr>& inputs, 
 struct WitnessSchedule {
     struct Range { uint32_t lo, hi; };
     uint32_t n_threads = 1;
+    bool serial_tail = false;                               // the last level runs on the calling thread in program order
     std::vector<std::vector<std::vector<Range>>> plan;      // [level][thread] -> ranges
 
     void build(const PlanData& P, uint32_t threads) {
         n_threads = threads;
+        serial_tail = false;
         plan.clear();
         const uint32_t A = P.num_advice, n = P.n, nops = (uint32_t)P.wops.size();
         if (threads <= 1 || nops == 0) return;
@@ -600,11 +602,32 @@ struct WitnessSchedule {
             tasks[t].level = lv;
             n_levels = std::max(n_levels, lv + 1);
         }
+        // A program ends in a chain of glue (copies of the last hashes into their output cells, the range checks' limbs): a
+        // handful of ops per level, and a level costs every thread a barrier.  From the first level on after which all
+        // that is left is small, the rest runs on the calling thread in program order (an op's inputs come from earlier
+        // ops), behind one barrier instead of ten.
+        {
+            std::vector<uint64_t> ops_at(n_levels, 0);
+            for (auto& t : tasks) ops_at[t.level] += t.hi - t.lo;
+            uint32_t tail = n_levels;
+            uint64_t rest = 0;
+            while (tail > 1 && rest + ops_at[tail - 1] <= 64) rest += ops_at[--tail];
+            if (tail + 1 < n_levels) {
+                for (auto& t : tasks) if (t.level > tail) t.level = tail;
+                n_levels = tail + 1;
+                serial_tail = true;
+            }
+        }
         // 3. per level: longest tasks first onto the least loaded thread
         plan.assign(n_levels, std::vector<std::vector<Range>>(threads));
         for (uint32_t lv = 0; lv < n_levels; lv++) {
             std::vector<const Task*> at;
             for (auto& t : tasks) if (t.level == lv) at.push_back(&t);
+            if (serial_tail && lv + 1 == n_levels) {           // program order on thread 0
+                std::sort(at.begin(), at.end(), [](const Task* a, const Task* b) { return a->lo < b->lo; });
+                for (const Task* t : at) plan[lv][0].push_back({t->lo, t->hi});
+                continue;
+            }
             std::sort(at.begin(), at.end(), [](const Task* a, const Task* b) { return a->hi - a->lo > b->hi - b->lo; });
             std::vector<uint64_t> load(threads, 0);
             for (const Task* t : at) {
