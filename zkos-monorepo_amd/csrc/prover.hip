@@ -1172,8 +1172,93 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     Fr* const instcol = grid + (size_t)A * n;           // rows past the instances stay zero (cleared at creation)
     uint32_t rows_now;                                  // leading rows of the advice columns that this proof may fill
     Transcript tr(pk->vk_digest);
-    std::vector<G1Affine> pts(std::max<uint32_t>({A + 1, 2 * L, S + L + 1, P.degree}));
+    std::vector<G1Affine> pts(std::max<uint32_t>({A + 2 * L + 1, S + L + 1, P.degree}));
     std::vector<Fr> chal(P.challenge_phase.size(), Fr::zero());
+    ProgArgs pa;
+    pa.out_raw = nullptr;
+    pa.consts = pk->consts;
+    pa.adv_q = pk->adv_q; pa.fix_q = pk->fix_q; pa.inst_q = pk->inst_q;
+    auto lagrange_domain = [&](ProgArgs& a) {
+        a.adv_base = V(0); a.adv_stride = n;
+        a.fix_base = pk->fixed_vals; a.fix_stride = n;
+        a.inst_base = V(I_INST);
+        a.size_mask = n - 1; a.rot_step = 1; a.hi_mask = 0;
+    };
+    auto extended_domain = [&](ProgArgs& a) {
+        a.adv_base = CS(0); a.adv_stride = ne;
+        a.fix_base = pk->fixed_cos; a.fix_stride = ne;
+        a.inst_base = CS(I_INST);
+        a.size_mask = n - 1; a.rot_step = 1; a.hi_mask = ~(n - 1);
+    };
+    std::vector<Fr> hb;                                 // host staging of blinding values
+    // P3's device work up to the permuted columns V(I_PIN ...): compress the lookups' expressions with theta, sort, permute,
+    // blind.  Returns the per-lookup error words (pinned; valid once the stream has passed the flags kernel).
+    auto lookup_columns = [&](const Fr& theta) -> uint32_t* {
+        for (uint32_t l = 0; l < L; l++) {
+            const LookupPlan& lk = P.lookups[l];
+            lagrange_domain(pa);
+            pa.mult = theta; pa.acc_in = nullptr;
+            pa.prog = pk->lk_in_prog[l]; pa.n_instr = (uint32_t)lk.in_prog.size(); pa.nslots = lk.in_slots;
+            // the compressed expressions in Montgomery form and, for the sort, as plain integers in the same pass;
+            // input and table expression in one launch
+            pa.out = pr->cin + (size_t)l * n;
+            pa.out_raw = pr->sort_raw + (size_t)(2 * l) * n;
+            ProgArgs pt = pa;
+            pt.prog = pk->lk_tab_prog[l]; pt.n_instr = (uint32_t)lk.tab_prog.size(); pt.nslots = lk.tab_slots;
+            pt.out = pr->ctab + (size_t)l * n;
+            pt.out_raw = pr->sort_raw + (size_t)(2 * l + 1) * n;
+            launch_prog(st, pa, n, pr->throughput, &pt);
+            pa.out_raw = nullptr;
+        }
+        pr->timers.begin(KID_RANK_SORT, st);
+        SHP_REQUIRE(2 * L <= pr->sc_cnt, SHP_ERR_INVALID_ARG, "prove: too many lookups for the sort scratch");
+        hipLaunchKernelGGL(sort_tiles_kernel, dim3(ceil_div(u, SORT_TILE), 2 * L), dim3(512), 0, st, pr->sort_raw, pr->sc_pre,
+                           pr->rank, u, (size_t)n);
+        uint32_t G = 1;
+        while (G < ceil_div(u, SORT_TILE)) G <<= 1;                       // <= 64 for k <= 16
+        hipLaunchKernelGGL(rank_from_tiles_kernel, dim3(ceil_div((size_t)u * G, 256), 2 * L), dim3(256), 0, st, pr->sort_raw,
+                           pr->sc_pre, pr->rank, pr->sort_out, u, (size_t)n, G);
+        pr->timers.end(st);
+        hb.clear();
+        for (uint32_t l = 0; l < L; l++) {
+            for (uint32_t j = 0; j < 2 * nb; j++) hb.push_back(draw());   // permuted input rows, then table rows
+            ctr += 2;                                                     // two (unused) commitment blinds
+        }
+        const Fr* lk_blinds = (const Fr*)staged(hb.data(), hb.size() * sizeof(Fr));
+        uint32_t* herr = (uint32_t*)pr->stage_alloc(L * sizeof(uint32_t));   // written by the kernel, read after the commit
+        for (uint32_t l = 0; l < L; l++) herr[l] = 0;
+        uint32_t nt = std::min<uint32_t>(1024, n);
+        // sorted input of lookup l at sort_out[2l], sorted table at sort_out[2l+1]
+        LookupPermuteArgs lp;
+        lp.pin_all = V(I_PIN); lp.ptab_all = V(I_PIN + 1); lp.pstride = (size_t)2 * n; lp.scratch_all = pr->rep_scratch;
+        lp.blinds = lk_blinds; lp.err = herr; lp.done = pr->lk_done;
+        hipLaunchKernelGGL(lookup_flags_kernel, dim3(ceil_div(u, nt), L), dim3(nt), 0, st, pr->sort_out, pr->sort_out + n,
+                           (size_t)2 * n, u, n, pr->rank, lp);
+        return herr;
+    };
+    // A lookup over single expressions (one input, one table expression: a range check) is not compressed with theta at
+    // all, so its permuted columns depend on the advice columns alone: they are built before the advice commitment and
+    // committed in the SAME launch -- one commitment launch and one host round trip less per proof.  The transcript still
+    // takes the advice points, squeezes theta, then takes the permuted columns' points.
+    bool early_lookups = L > 0 && !phased;
+    for (const LookupPlan& lk : P.lookups) early_lookups = early_lookups && lk.m == 1;
+    {
+        static const bool off = getenv("SHP_EARLY_LOOKUPS") && atoi(getenv("SHP_EARLY_LOOKUPS")) == 0;
+        if (off) early_lookups = false;
+    }
+    uint32_t* early_err = nullptr;
+    // every job of one launch, through the pool's combiner when this lane has one
+    auto commit_jobs = [&](MsmJob* jobs, uint32_t count) {
+        bool direct = true;
+        for (uint32_t j = 0; j < count; j++) direct = direct && jobs[j].m->direct;
+        if (!direct) {
+            for (uint32_t j = 0; j < count; j++) msm_run_ws(jobs[j].m, pr->msm_ws, jobs[j].scalars, n, n, jobs[j].batch, jobs[j].h_out, st);
+        } else if (pr->comb) {
+            pr->comb->run(jobs, count, st, pr->comb_event);
+        } else {
+            msm_run_jobs(jobs, count, pr->msm_ws, st);
+        }
+    };
     const Fr* advice_once = in.advice;                  // one phase, no challenge: the callback is asked once
     if (!phased && in.phase_fn) {
         advice_once = (const Fr*)in.phase_fn(in.phase_user, 0, nullptr, 0);
@@ -1232,10 +1317,18 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         // ---- P2: advice commitments.  The random polynomial of P7 depends on no challenge: its
         // coefficients (blinding stream position known up front) and its commitment ride in the same launch.
         const MsmRows adv_rows{rows_now, u, n - u};       // assigned rows + blinding rows; the rest is zero
+        MsmJob jobs[3];
+        uint32_t n_jobs = 0;
+        jobs[n_jobs++] = MsmJob{srs->msm_gl, V(0), n, A, adv_rows, pts.data()};
         if (split_commits) {
             // witness rows and instances in one dispatch; the random polynomial is on its way already
             ingest(0, A + 1, rows_now, (uint32_t)instances.size());
-            commit_launch(pr->msm_ws, srs->msm_gl, V(0), A, pts.data(), &adv_rows);
+            if (early_lookups) {
+                early_err = lookup_columns(Fr::zero());
+                jobs[n_jobs++] = MsmJob{srs->msm_gl, V(I_PIN), n, 2 * L, MsmRows{n, 0, 0}, pts.data() + A};
+            }
+            pr->msm_ws.poll_results = true;
+            msm_launch_jobs(jobs, n_jobs, pr->msm_ws, st);
             msm_finish_jobs(pr->msm_ws_rand, st);
             msm_finish_jobs(pr->msm_ws, st);
         } else {
@@ -1243,8 +1336,12 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             // polynomial's commitment rides in the advice columns' launch
             ingest(0, A + 2, rows_now, (uint32_t)instances.size());
             rand_values();
-            commit(srs->msm_gl, V(0), A, pts.data(), &adv_rows, srs->msm_gl, rand_lag, 1);
-            rand_comm = pts[A];
+            if (early_lookups) {
+                early_err = lookup_columns(Fr::zero());
+                jobs[n_jobs++] = MsmJob{srs->msm_gl, V(I_PIN), n, 2 * L, MsmRows{n, 0, 0}, pts.data() + A};
+            }
+            jobs[n_jobs++] = MsmJob{srs->msm_gl, rand_lag, n, 1, MsmRows{n, 0, 0}, &rand_comm};
+            commit_jobs(jobs, n_jobs);
         }
         for (uint32_t c = 0; c < A; c++) tr.write_point(pts[c].x, pts[c].y);
     } else {
@@ -1338,70 +1435,14 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     }
     const Fr theta = tr.squeeze();
 
-    ProgArgs pa;
-    pa.out_raw = nullptr;
-    pa.consts = pk->consts;
     if (phased) {                                       // every challenge is known: they complete the lane's constant table
         h2d(pr->consts_lane + P.consts.size(), chal.data(), chal.size() * sizeof(Fr));
         pa.consts = pr->consts_lane;
     }
-    pa.adv_q = pk->adv_q; pa.fix_q = pk->fix_q; pa.inst_q = pk->inst_q;
-    auto lagrange_domain = [&](ProgArgs& a) {
-        a.adv_base = V(0); a.adv_stride = n;
-        a.fix_base = pk->fixed_vals; a.fix_stride = n;
-        a.inst_base = V(I_INST);
-        a.size_mask = n - 1; a.rot_step = 1; a.hi_mask = 0;
-    };
-    auto extended_domain = [&](ProgArgs& a) {
-        a.adv_base = CS(0); a.adv_stride = ne;
-        a.fix_base = pk->fixed_cos; a.fix_stride = ne;
-        a.inst_base = CS(I_INST);
-        a.size_mask = n - 1; a.rot_step = 1; a.hi_mask = ~(n - 1);
-    };
     pc.mark("advice_msm");
-    // ---- P3: lookups -- compress, permute, commit
-    std::vector<Fr> hb;                                 // host staging of blinding values
-    if (L) {
-        for (uint32_t l = 0; l < L; l++) {
-            const LookupPlan& lk = P.lookups[l];
-            lagrange_domain(pa);
-            pa.mult = theta; pa.acc_in = nullptr;
-            pa.prog = pk->lk_in_prog[l]; pa.n_instr = (uint32_t)lk.in_prog.size(); pa.nslots = lk.in_slots;
-            // the compressed expressions in Montgomery form and, for the sort, as plain integers in the same pass;
-            // input and table expression in one launch
-            pa.out = pr->cin + (size_t)l * n;
-            pa.out_raw = pr->sort_raw + (size_t)(2 * l) * n;
-            ProgArgs pt = pa;
-            pt.prog = pk->lk_tab_prog[l]; pt.n_instr = (uint32_t)lk.tab_prog.size(); pt.nslots = lk.tab_slots;
-            pt.out = pr->ctab + (size_t)l * n;
-            pt.out_raw = pr->sort_raw + (size_t)(2 * l + 1) * n;
-            launch_prog(st, pa, n, pr->throughput, &pt);
-            pa.out_raw = nullptr;
-        }
-        pr->timers.begin(KID_RANK_SORT, st);
-        SHP_REQUIRE(2 * L <= pr->sc_cnt, SHP_ERR_INVALID_ARG, "prove: too many lookups for the sort scratch");
-        hipLaunchKernelGGL(sort_tiles_kernel, dim3(ceil_div(u, SORT_TILE), 2 * L), dim3(512), 0, st, pr->sort_raw, pr->sc_pre,
-                           pr->rank, u, (size_t)n);
-        uint32_t G = 1;
-        while (G < ceil_div(u, SORT_TILE)) G <<= 1;                       // <= 64 for k <= 16
-        hipLaunchKernelGGL(rank_from_tiles_kernel, dim3(ceil_div((size_t)u * G, 256), 2 * L), dim3(256), 0, st, pr->sort_raw,
-                           pr->sc_pre, pr->rank, pr->sort_out, u, (size_t)n, G);
-        pr->timers.end(st);
-        hb.clear();
-        for (uint32_t l = 0; l < L; l++) {
-            for (uint32_t j = 0; j < 2 * nb; j++) hb.push_back(draw());   // permuted input rows, then table rows
-            ctr += 2;                                                     // two (unused) commitment blinds
-        }
-        const Fr* lk_blinds = (const Fr*)staged(hb.data(), hb.size() * sizeof(Fr));
-        uint32_t* herr = (uint32_t*)pr->stage_alloc(L * sizeof(uint32_t));   // written by the kernel, read after the commit
-        for (uint32_t l = 0; l < L; l++) herr[l] = 0;
-        uint32_t nt = std::min<uint32_t>(1024, n);
-        // sorted input of lookup l at sort_out[2l], sorted table at sort_out[2l+1]
-        LookupPermuteArgs lp;
-        lp.pin_all = V(I_PIN); lp.ptab_all = V(I_PIN + 1); lp.pstride = (size_t)2 * n; lp.scratch_all = pr->rep_scratch;
-        lp.blinds = lk_blinds; lp.err = herr; lp.done = pr->lk_done;
-        hipLaunchKernelGGL(lookup_flags_kernel, dim3(ceil_div(u, nt), L), dim3(nt), 0, st, pr->sort_out, pr->sort_out + n,
-                           (size_t)2 * n, u, n, pr->rank, lp);
+    // ---- P3: lookups -- compress, permute, commit (unless their columns went out with the advice columns' launch)
+    if (L && !early_lookups) {
+        uint32_t* const herr = lookup_columns(theta);
         if (split_commits) {
             commit_launch(pr->msm_ws, srs->msm_gl, V(I_PIN), 2 * L, pts.data());
             msm_finish_jobs(pr->msm_ws, st);
@@ -1411,6 +1452,10 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         for (uint32_t l = 0; l < L; l++)
             SHP_REQUIRE(herr[l] == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
         for (uint32_t i = 0; i < 2 * L; i++) tr.write_point(pts[i].x, pts[i].y);
+    } else if (L) {
+        for (uint32_t l = 0; l < L; l++)
+            SHP_REQUIRE(early_err[l] == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
+        for (uint32_t i = 0; i < 2 * L; i++) tr.write_point(pts[A + i].x, pts[A + i].y);
     }
     pc.mark("lookup");
     // ---- P4
