@@ -1232,6 +1232,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         LookupPermuteArgs lp;
         lp.pin_all = V(I_PIN); lp.ptab_all = V(I_PIN + 1); lp.pstride = (size_t)2 * n; lp.scratch_all = pr->rep_scratch;
         lp.blinds = lk_blinds; lp.err = herr; lp.done = pr->lk_done;
+        lp.tmont_all = pr->sort_raw + n; lp.tmont_stride = (size_t)2 * n;     // the unsorted table keys are dead by now
         hipLaunchKernelGGL(lookup_flags_kernel, dim3(ceil_div(u, nt), L), dim3(nt), 0, st, pr->sort_out, pr->sort_out + n,
                            (size_t)2 * n, u, n, pr->rank, lp);
         return herr;

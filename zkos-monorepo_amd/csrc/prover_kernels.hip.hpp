@@ -671,26 +671,42 @@ __device__ __forceinline__ bool bsearch_raw(const Fr* arr, uint32_t count, const
     return false;
 }
 
-__device__ __forceinline__ uint32_t block_scan_u32_excl(uint32_t v, uint32_t* sh, uint32_t t, uint32_t nt, uint32_t* total) {
-    sh[t] = v;
-    __syncthreads();
-    for (uint32_t off = 1; off < nt; off <<= 1) {
-        uint32_t x = sh[t];
-        if (t >= off) x += sh[t - off];
-        __syncthreads();
-        sh[t] = x;
-        __syncthreads();
+// exclusive prefix sums of TWO counters per thread over the workgroup: shuffles inside a wave, one LDS step across the
+// waves -- three barriers where a Hillis-Steele scan in LDS takes twenty per counter (on a 1024-thread workgroup a
+// barrier is what the time goes into)
+__device__ __forceinline__ void block_scan2_u32_excl(uint32_t& a, uint32_t& b, uint32_t* sh /* [>= 2 * waves + 2] */, uint32_t t,
+                                                     uint32_t nt, uint32_t* total_a, uint32_t* total_b) {
+    const uint32_t lane = t & 63, wave = t >> 6, waves = (nt + 63) >> 6;
+    uint32_t ia = a, ib = b;                                   // inclusive scans inside the wave
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        const uint32_t ua = __shfl_up(ia, off), ub = __shfl_up(ib, off);
+        if (lane >= off) { ia += ua; ib += ub; }
     }
-    uint32_t r = t ? sh[t - 1] : 0;
-    *total = sh[nt - 1];
+    if (lane == 63 || t == nt - 1) { sh[2 * wave] = ia; sh[2 * wave + 1] = ib; }
     __syncthreads();
-    return r;
+    if (t == 0) {                                              // at most sixteen waves: a serial pass
+        uint32_t ra = 0, rb = 0;
+        for (uint32_t w = 0; w < waves; w++) {
+            const uint32_t xa = sh[2 * w], xb = sh[2 * w + 1];
+            sh[2 * w] = ra; sh[2 * w + 1] = rb;
+            ra += xa; rb += xb;
+        }
+        sh[2 * waves] = ra; sh[2 * waves + 1] = rb;
+    }
+    __syncthreads();
+    const uint32_t base_a = sh[2 * wave], base_b = sh[2 * wave + 1];
+    *total_a = sh[2 * waves];
+    *total_b = sh[2 * waves + 1];
+    a = base_a + ia - a;
+    b = base_b + ib - b;
+    __syncthreads();
 }
 
 // a = sorted input (raw), tb = sorted table (raw); writes permuted input / table (Montgomery)
 // rows [0,u) and the blinding rows [u,n) of both; err[l] != 0 when the input of lookup l is not in the table (one plain
 // store per workgroup: `err` and `blinds` may live in pinned host memory, read and written over the host link).
 // One workgroup per lookup (the last one of lookup_flags_kernel): only prefix sums over the flags and the scatter are left here.
+constexpr uint32_t LOOKUP_REP_LDS = 8192;
 struct LookupPermuteArgs {
     Fr *pin_all, *ptab_all;
     size_t pstride;
@@ -698,43 +714,50 @@ struct LookupPermuteArgs {
     const Fr* blinds;
     uint32_t* err;
     uint32_t* done;          // per lookup: flag workgroups finished (zero between launches)
+    Fr* tmont_all;           // scratch, lookup l at l * tmont_stride: the sorted table in Montgomery form, written by the flag
+    size_t tmont_stride;     // pass of every workgroup so that the one permuting workgroup only copies
 };
-__device__ __forceinline__ void lookup_permute_body(const Fr* a_all, const Fr* tb_all, size_t sstride, uint32_t u, uint32_t n,
+__device__ __forceinline__ void lookup_permute_body(const Fr* tmont, uint32_t u, uint32_t n,
                                                     Fr* pin_all, Fr* ptab_all, size_t pstride, uint32_t* scratch_all,
                                                     const uint32_t* flags_all, const Fr* blinds, uint32_t* err, uint32_t l,
-                                                    uint32_t* sh /* [1024] */) {
+                                                    uint32_t* sh /* [1024] */, uint32_t* rep_lds /* [LOOKUP_REP_LDS] */) {
     const uint32_t t = threadIdx.x, nt = blockDim.x;
-    const Fr* tb = tb_all + (size_t)l * sstride;
     Fr* pin = pin_all + (size_t)l * pstride;
     Fr* ptab = ptab_all + (size_t)l * pstride;
-    uint32_t* rep = scratch_all + (size_t)l * n;        // rows of repeated inputs, ascending
+    // rows of repeated inputs, ascending: in LDS when they fit (a round trip through global memory otherwise)
+    uint32_t* rep = u <= LOOKUP_REP_LDS ? rep_lds : scratch_all + (size_t)l * n;
     const uint32_t* fl = flags_all + (size_t)l * n;
     const uint32_t per = (u + nt - 1) / nt;
     const uint32_t r0 = t * per < u ? t * per : u, r1 = r0 + per < u ? r0 + per : u;
+    // a thread's flags packed four bits apiece: read once (up to sixteen rows a thread; beyond that the loops reload)
+    uint64_t packed = 0;
+    const bool cached = per <= 16;
     uint32_t nrep = 0, nkeep = 0, bad = 0;
     for (uint32_t i = r0; i < r1; i++) {
         const uint32_t f = fl[i];
+        if (cached) packed |= (uint64_t)(f & 15u) << (4 * (i - r0));
         nrep += (f & 1u) ? 0u : 1u;
         bad += (f >> 1) & 1u;
         nkeep += (f >> 2) & 1u;
     }
+    auto flag_of = [&](uint32_t i) -> uint32_t { return cached ? (uint32_t)(packed >> (4 * (i - r0))) & 15u : fl[i]; };
     const int any_bad = __syncthreads_or(bad != 0);
     uint32_t tot_rep, tot_keep;
-    uint32_t rep_off = block_scan_u32_excl(nrep, sh, t, nt, &tot_rep);
-    uint32_t keep_off = block_scan_u32_excl(nkeep, sh, t, nt, &tot_keep);
+    uint32_t rep_off = nrep, keep_off = nkeep;
+    block_scan2_u32_excl(rep_off, keep_off, sh, t, nt, &tot_rep, &tot_keep);
     if (t == 0) err[l] = (any_bad ? 1u : 0u) | (tot_rep != tot_keep ? 2u : 0u);
     // list the repeated rows (the permuted input, and the table entries of first occurrences, were written by the flag
     // pass of every workgroup: only what needs the prefix sums is left to this one)
     uint32_t q = rep_off;
     for (uint32_t i = r0; i < r1; i++)
-        if (!(fl[i] & 1u)) rep[q++] = i;
+        if (!(flag_of(i) & 1u)) rep[q++] = i;
     __threadfence_block();
     __syncthreads();
     // leftover table entries (ascending) go to the repeated rows taken from the END
     q = keep_off;
     for (uint32_t i = r0; i < r1; i++) {
-        if (fl[i] & 4u) {
-            if (q < tot_rep) st(ptab + rep[tot_rep - 1 - q], Fr::from_raw(ld(tb + i)));
+        if (flag_of(i) & 4u) {
+            if (q < tot_rep) st(ptab + rep[tot_rep - 1 - q], ld(tmont + i));
             q++;
         }
     }
@@ -754,6 +777,7 @@ __device__ __forceinline__ void lookup_permute_body(const Fr* a_all, const Fr* t
 __global__ __launch_bounds__(1024) void lookup_flags_kernel(const Fr* a_all, const Fr* tb_all, size_t sstride, uint32_t u,
                                                             uint32_t n, uint32_t* flags_all, LookupPermuteArgs pa) {
     __shared__ uint32_t sh[1024];
+    __shared__ uint32_t rep_lds[LOOKUP_REP_LDS];
     __shared__ uint32_t is_last;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
     if (i < u) {
@@ -773,6 +797,7 @@ __global__ __launch_bounds__(1024) void lookup_flags_kernel(const Fr* a_all, con
         const Fr am = Fr::from_raw(ai);
         st(pa.pin_all + (size_t)l * pa.pstride + i, am);
         if (f & 1u) st(pa.ptab_all + (size_t)l * pa.pstride + i, am);
+        if (f & 4u) st(pa.tmont_all + (size_t)l * pa.tmont_stride + i, Fr::from_raw(ti));
     }
     __threadfence();
     __syncthreads();
@@ -781,8 +806,8 @@ __global__ __launch_bounds__(1024) void lookup_flags_kernel(const Fr* a_all, con
     if (!is_last) return;
     __threadfence();
     if (threadIdx.x == 0) pa.done[l] = 0;
-    lookup_permute_body(a_all, tb_all, sstride, u, n, pa.pin_all, pa.ptab_all, pa.pstride, pa.scratch_all, flags_all, pa.blinds,
-                        pa.err, l, sh);
+    lookup_permute_body(pa.tmont_all + (size_t)l * pa.tmont_stride, u, n, pa.pin_all, pa.ptab_all, pa.pstride, pa.scratch_all, flags_all, pa.blinds,
+                        pa.err, l, sh, rep_lds);
 }
 
 // ------------------------------------------------------------------ quotient terms (extended domain)
