@@ -509,7 +509,9 @@ struct WitnessSchedule {
     bool serial_tail = false;                               // the last level runs on the calling thread in program order
     std::vector<std::vector<std::vector<Range>>> plan;      // [level][thread] -> ranges
 
-    void build(const PlanData& P, uint32_t threads) {
+    // spare_main: the calling thread gets no tasks of its own (it has kernels to launch while the helpers work) -- only
+    // the serial tail
+    void build(const PlanData& P, uint32_t threads, bool spare_main = false) {
         n_threads = threads;
         serial_tail = false;
         plan.clear();
@@ -630,9 +632,10 @@ struct WitnessSchedule {
             }
             std::sort(at.begin(), at.end(), [](const Task* a, const Task* b) { return a->hi - a->lo > b->hi - b->lo; });
             std::vector<uint64_t> load(threads, 0);
+            const uint32_t first = spare_main && threads > 1 ? 1 : 0;
             for (const Task* t : at) {
-                uint32_t best = 0;
-                for (uint32_t th = 1; th < threads; th++) if (load[th] < load[best]) best = th;
+                uint32_t best = first;
+                for (uint32_t th = first + 1; th < threads; th++) if (load[th] < load[best]) best = th;
                 plan[lv][best].push_back({t->lo, t->hi});
                 load[best] += t->hi - t->lo;
             }
@@ -707,7 +710,8 @@ struct WitnessWorkers {
             levels(tid);
         }
     }
-    void run(const PlanData& P_, const std::vector<Fr>& in, Fr* g, const WitnessSchedule& sc) {
+    // start: the helpers begin; finish: the calling thread does its share and leaves with the last level complete
+    void start(const PlanData& P_, const std::vector<Fr>& in, Fr* g, const WitnessSchedule& sc) {
         P = &P_; inputs = &in; grid = g; sched = &sc;
         base = arrivals.load(std::memory_order_acquire);
         {
@@ -715,7 +719,11 @@ struct WitnessWorkers {
             gen.fetch_add(1, std::memory_order_acq_rel);
         }
         cv.notify_all();
-        levels(0);
+    }
+    void finish() { levels(0); }
+    void run(const PlanData& P_, const std::vector<Fr>& in, Fr* g, const WitnessSchedule& sc) {
+        start(P_, in, g, sc);
+        finish();
     }
 };
 
@@ -772,6 +780,14 @@ struct shp_prover {
     // a pool's cross-lane MSM combiner (null: this lane launches its own commitments) and the event that hands
     // the lane's stream position over to it
     Fr* consts_lane = nullptr;             // several phases: the key's constants + this proof's challenges
+    // A lone proof builds the permuted columns of its single-expression lookups WHILE the host still runs the rest of the
+    // witness program: the few witness ops those lookups' input columns depend on (early_ranges, program order) run first,
+    // the columns (early_cols) go to the device and the lookup kernels run on a second stream, beside the random
+    // polynomial's commitment.  Empty ranges: the plan does not allow it (see early_lookup_ops).
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev2 = nullptr;
+    std::vector<WitnessSchedule::Range> early_ranges;
+    std::vector<uint32_t> early_cols;
     bool throughput = false;               // shp_prover_mode(1): scheduling choices of a pool lane
     bool keep_phases = false;
     std::vector<std::pair<const char*, double>> last_phases;   // host phase clock of the last proof (profiling on)
@@ -791,6 +807,8 @@ struct shp_prover {
     }
     ~shp_prover() {
         if (comb_event) (void)hipEventDestroy(comb_event);
+        if (ev2) (void)hipEventDestroy(ev2);
+        if (st2) (void)hipStreamDestroy(st2);
         stage.release();
         h_rand.release();
         for (void* p : owned) (void)hipFree(p);
@@ -801,11 +819,62 @@ struct shp_prover {
     }
 };
 
+// The witness ops that the input columns of the plan's lookups depend on, as ranges in program order, and those columns.
+// Nothing (empty ranges) unless every lookup is over single expressions without public inputs, the plan has one phase,
+// and the ops are few (range-check limbs come from the inputs through a handful of shifts and masks, not through the
+// hashes): then running them ahead of the program costs microseconds and hides the lookups' sort and permutation.
+static void early_lookup_ops(const PlanData& P, std::vector<WitnessSchedule::Range>& ranges, std::vector<uint32_t>& cols) {
+    ranges.clear();
+    cols.clear();
+    if (P.phased() || P.lookups.empty() || P.wops.empty()) return;
+    const uint32_t A = P.num_advice, n = P.n;
+    std::vector<uint8_t> is_col(A, 0);
+    for (const LookupPlan& lk : P.lookups) {
+        if (lk.m != 1) return;
+        for (const auto* prog : {&lk.in_prog, &lk.tab_prog})
+            for (const Instr& in : *prog) {
+                if (in.op == OP_INST || in.op == OP_CHAL) return;
+                if (in.op == OP_ADV) is_col[P.adv_q[in.a].col] = 1;
+            }
+    }
+    // backwards over the program: an op is kept when something kept later reads what it writes
+    const size_t cells = (size_t)A * n + std::max<uint32_t>(P.n_wscratch, 1);
+    std::vector<uint8_t> needed(cells, 0);
+    for (uint32_t c = 0; c < A; c++)
+        if (is_col[c]) std::fill(needed.begin() + (size_t)c * n, needed.begin() + (size_t)(c + 1) * n, 1);
+    auto id = [&](uint32_t c, uint32_t r) { return (size_t)c * n + r; };   // the scratch row is "column" A
+    std::vector<uint8_t> keep(P.wops.size(), 0);
+    size_t kept = 0;
+    for (size_t i = P.wops.size(); i-- > 0;) {
+        const WOp& w = P.wops[i];
+        const size_t d = id(w.dc, w.dr);
+        if (!needed[d]) continue;
+        keep[i] = 1;
+        kept++;
+        needed[d] = 0;                                   // what was written before this op is another value
+        switch (w.op) {
+            case W_INPUT: case W_CONST: case W_CHAL: break;
+            case W_ADD: case W_SUB: case W_MUL: needed[id(w.ac, w.ar)] = 1; needed[id(w.bc, w.br)] = 1; break;
+            default: needed[id(w.ac, w.ar)] = 1; break;
+        }
+    }
+    if (kept == 0 || kept > 4096 || kept * 8 > P.wops.size()) return;     // not cheap: leave the program alone
+    for (uint32_t i = 0; i < P.wops.size();) {
+        if (!keep[i]) { i++; continue; }
+        uint32_t j = i + 1;
+        while (j < P.wops.size() && keep[j]) j++;
+        ranges.push_back({i, j});
+        i = j;
+    }
+    for (uint32_t c = 0; c < A; c++)
+        if (is_col[c]) cols.push_back(c);
+}
+
 static void set_witness_threads(shp_prover* pr, uint32_t threads) {
     threads = std::max<uint32_t>(1, std::min<uint32_t>(threads, 16));
     pr->wworkers.reset();
     if (pr->pk->plan.phased()) return;     // a phase's part of the program runs in order on the calling thread
-    pr->wsched.build(pr->pk->plan, threads);
+    pr->wsched.build(pr->pk->plan, threads, !pr->early_ranges.empty() && threads >= 3);
     if (pr->wsched.n_threads > 1 && !pr->wsched.plan.empty())
         pr->wworkers.reset(new WitnessWorkers(pr->wsched.n_threads, pr->pk->plan.n_wscratch));
 }
@@ -866,6 +935,11 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->msm_ws.timers = &pr->timers;
     pr->msm_ws.poll_results = poll_results_enabled();       // a new lane is a latency lane until shp_prover_mode says otherwise
     pr->wscratch.assign(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
+    early_lookup_ops(P, pr->early_ranges, pr->early_cols);
+    if (!pr->early_ranges.empty()) {
+        SHP_HIP(hipStreamCreateWithFlags(&pr->st2, hipStreamNonBlocking));
+        SHP_HIP(hipEventCreateWithFlags(&pr->ev2, hipEventDisableTiming));
+    }
     if (P.phased()) {
         const size_t cnt = P.consts.size() + P.challenge_phase.size();
         pr->consts_lane = pr->dalloc<Fr>(cnt);
@@ -1143,7 +1217,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     // position known up front) are drawn on the device and its commitment runs while the host executes the witness program
     const uint64_t ctr_rand = (uint64_t)A * nb + A + (uint64_t)L * (2 * nb + 2) + (uint64_t)(S + L) * (bf + 1);
     G1Affine rand_comm;
-    auto ingest = [&](uint32_t y0, uint32_t rows, uint32_t rows_now_, uint32_t n_inst) {
+    auto ingest = [&](uint32_t y0, uint32_t rows, uint32_t rows_now_, uint32_t n_inst, hipStream_t on = nullptr) {
         IngestArgs ia;
         ia.grid = pr->h_grid; ia.vals = V(0); ia.inst = V(I_INST); ia.rand_poly = pr->rand_poly; ia.h_rand = nullptr;
         ia.n = n; ia.n_adv = A; ia.rows_now = rows_now_; ia.u = u; ia.n_inst = n_inst; ia.y0 = y0;
@@ -1154,7 +1228,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             memcpy(pr->h_rand.p, in.draws + ctr_rand, (size_t)n * sizeof(Fr));
             ia.h_rand = pr->h_rand.as<Fr>();
         }
-        hipLaunchKernelGGL(ingest_kernel, dim3(ceil_div(n, 256), rows), dim3(256), 0, st, ia);
+        hipLaunchKernelGGL(ingest_kernel, dim3(ceil_div(n, 256), rows), dim3(256), 0, on ? on : st, ia);
     };
     // Every commitment of a proof goes through the LAGRANGE basis and its one multiples table: the polynomials that exist
     // as coefficients (this one, the quotient pieces) are transformed to their values on the domain first -- the same group
@@ -1193,7 +1267,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     std::vector<Fr> hb;                                 // host staging of blinding values
     // P3's device work up to the permuted columns V(I_PIN ...): compress the lookups' expressions with theta, sort, permute,
     // blind.  Returns the per-lookup error words (pinned; valid once the stream has passed the flags kernel).
-    auto lookup_columns = [&](const Fr& theta) -> uint32_t* {
+    auto lookup_columns = [&](const Fr& theta, hipStream_t ls) -> uint32_t* {
         for (uint32_t l = 0; l < L; l++) {
             const LookupPlan& lk = P.lookups[l];
             lagrange_domain(pa);
@@ -1207,18 +1281,18 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             pt.prog = pk->lk_tab_prog[l]; pt.n_instr = (uint32_t)lk.tab_prog.size(); pt.nslots = lk.tab_slots;
             pt.out = pr->ctab + (size_t)l * n;
             pt.out_raw = pr->sort_raw + (size_t)(2 * l + 1) * n;
-            launch_prog(st, pa, n, pr->throughput, &pt);
+            launch_prog(ls, pa, n, pr->throughput, &pt);
             pa.out_raw = nullptr;
         }
-        pr->timers.begin(KID_RANK_SORT, st);
+        pr->timers.begin(KID_RANK_SORT, ls);
         SHP_REQUIRE(2 * L <= pr->sc_cnt, SHP_ERR_INVALID_ARG, "prove: too many lookups for the sort scratch");
-        hipLaunchKernelGGL(sort_tiles_kernel, dim3(ceil_div(u, SORT_TILE), 2 * L), dim3(512), 0, st, pr->sort_raw, pr->sc_pre,
+        hipLaunchKernelGGL(sort_tiles_kernel, dim3(ceil_div(u, SORT_TILE), 2 * L), dim3(512), 0, ls, pr->sort_raw, pr->sc_pre,
                            pr->rank, u, (size_t)n);
         uint32_t G = 1;
         while (G < ceil_div(u, SORT_TILE)) G <<= 1;                       // <= 64 for k <= 16
-        hipLaunchKernelGGL(rank_from_tiles_kernel, dim3(ceil_div((size_t)u * G, 256), 2 * L), dim3(256), 0, st, pr->sort_raw,
+        hipLaunchKernelGGL(rank_from_tiles_kernel, dim3(ceil_div((size_t)u * G, 256), 2 * L), dim3(256), 0, ls, pr->sort_raw,
                            pr->sc_pre, pr->rank, pr->sort_out, u, (size_t)n, G);
-        pr->timers.end(st);
+        pr->timers.end(ls);
         hb.clear();
         for (uint32_t l = 0; l < L; l++) {
             for (uint32_t j = 0; j < 2 * nb; j++) hb.push_back(draw());   // permuted input rows, then table rows
@@ -1233,7 +1307,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         lp.pin_all = V(I_PIN); lp.ptab_all = V(I_PIN + 1); lp.pstride = (size_t)2 * n; lp.scratch_all = pr->rep_scratch;
         lp.blinds = lk_blinds; lp.err = herr; lp.done = pr->lk_done;
         lp.tmont_all = pr->sort_raw + n; lp.tmont_stride = (size_t)2 * n;     // the unsorted table keys are dead by now
-        hipLaunchKernelGGL(lookup_flags_kernel, dim3(ceil_div(u, nt), L), dim3(nt), 0, st, pr->sort_out, pr->sort_out + n,
+        hipLaunchKernelGGL(lookup_flags_kernel, dim3(ceil_div(u, nt), L), dim3(nt), 0, ls, pr->sort_out, pr->sort_out + n,
                            (size_t)2 * n, u, n, pr->rank, lp);
         return herr;
     };
@@ -1248,6 +1322,14 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         if (off) early_lookups = false;
     }
     uint32_t* early_err = nullptr;
+    bool lookups_ahead = false;
+    // positions in the blinding stream: advice column c's row r; the lookups' values (behind the advice columns' rows and
+    // unused blinds)
+    auto blind_of = [&](uint32_t c, uint32_t r) {
+        const uint64_t at = (uint64_t)c * nb + (r - u);
+        return in.draws ? in.draws[at] : fr_draw(key, at);
+    };
+    const uint64_t lookup_ctr0 = (uint64_t)A * nb + A, lookup_ctr1 = lookup_ctr0 + (uint64_t)L * (2 * nb + 2);
     // every job of one launch, through the pool's combiner when this lane has one
     auto commit_jobs = [&](MsmJob* jobs, uint32_t count) {
         bool direct = true;
@@ -1293,20 +1375,51 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
                 memset(grid, 0, (size_t)A * n * sizeof(Fr));
                 pr->grid_foreign = false;
             }
+            rows_now = P.adv_rows;
+            // the lookups' input columns ahead of the program, and their sort and permutation on the second stream while
+            // the program runs (a lone proof only; a proof that has rows of its predecessor to clear keeps the usual order)
+            const bool ahead = split_commits && early_lookups && !pr->early_ranges.empty() && rows_now >= pr->dev_rows;
+            // (the helpers read `inputs` and write the grid until finish() returns: on every path out of this block)
+            struct Joiner {
+                WitnessWorkers* w = nullptr;
+                void join() { if (w) { WitnessWorkers* x = w; w = nullptr; x->finish(); } }
+                ~Joiner() { join(); }
+            } started;
+            if (ahead) {
+                for (const auto& r : pr->early_ranges) run_witness_range(P, inputs, grid, pr->wscratch.data(), r.lo, r.hi);
+                for (uint32_t c : pr->early_cols)
+                    for (uint32_t r = u; r < n; r++) grid[(size_t)c * n + r] = blind_of(c, r);
+                // the helpers start on the program (it writes the same values into the cells above again: nothing reads
+                // them on the host meanwhile) while this thread queues the lookups' kernels
+                if (pr->wworkers) { pr->wworkers->start(P, inputs, grid, pr->wsched); started.w = pr->wworkers.get(); }
+                for (size_t k0 = 0; k0 < pr->early_cols.size();) {           // runs of consecutive columns
+                    size_t k1 = k0 + 1;
+                    while (k1 < pr->early_cols.size() && pr->early_cols[k1] == pr->early_cols[k1 - 1] + 1) k1++;
+                    ingest(pr->early_cols[k0], (uint32_t)(k1 - k0), rows_now, 0, pr->st2);
+                    k0 = k1;
+                }
+                ctr = lookup_ctr0;                            // the lookups' blinding values sit behind the advice columns'
+                early_err = lookup_columns(Fr::zero(), pr->st2);
+                SHP_REQUIRE(ctr == lookup_ctr1, SHP_ERR_INTERNAL, "prove: blinding stream position of the lookups");
+                ctr = 0;
+                SHP_HIP(hipEventRecord(pr->ev2, pr->st2));
+                lookups_ahead = true;
+            }
             // no per-proof clearing: the program writes the same cells every time (fixed plan), the blinding rows are
             // redrawn below, everything else has been zero since prover_create
-            if (pr->wworkers) pr->wworkers->run(P, inputs, grid, pr->wsched);
+            if (started.w) started.join();
+            else if (pr->wworkers) pr->wworkers->run(P, inputs, grid, pr->wsched);
             else run_witness_range(P, inputs, grid, pr->wscratch.data(), 0, (uint32_t)P.wops.size());
             instances.resize(P.instance_map.size());
             for (size_t i = 0; i < instances.size(); i++)
                 instances[i] = grid[(size_t)P.instance_map[i].first * n + P.instance_map[i].second];
-            rows_now = P.adv_rows;
         }
         pc.mark("run_witness");
         for (uint32_t c = 0; c < A; c++)
             for (uint32_t r = u; r < n; r++) grid[(size_t)c * n + r] = draw();
         pc.mark("blind_draws");
         ctr += A;                                           // one (unused) commitment blind per advice column
+        if (lookups_ahead) ctr = lookup_ctr1;               // drawn when the lookups were built
         for (size_t i = 0; i < instances.size(); i++) instcol[i] = instances[i];
         // only the rows this proof assigns and the blinding rows travel; the rest is zero on both sides
         if (A && rows_now < pr->dev_rows)                   // the previous proof filled more rows than this one
@@ -1323,11 +1436,21 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         jobs[n_jobs++] = MsmJob{srs->msm_gl, V(0), n, A, adv_rows, pts.data()};
         if (split_commits) {
             // witness rows and instances in one dispatch; the random polynomial is on its way already
-            ingest(0, A + 1, rows_now, (uint32_t)instances.size());
-            if (early_lookups) {
-                early_err = lookup_columns(Fr::zero());
-                jobs[n_jobs++] = MsmJob{srs->msm_gl, V(I_PIN), n, 2 * L, MsmRows{n, 0, 0}, pts.data() + A};
+            if (lookups_ahead) {
+                // every column but those that went ahead (they are being read on the second stream), then the instances
+                uint32_t c0 = 0;
+                for (size_t k0 = 0; k0 <= pr->early_cols.size(); k0++) {
+                    const uint32_t c1 = k0 < pr->early_cols.size() ? pr->early_cols[k0] : A;
+                    if (c1 > c0) ingest(c0, c1 - c0, rows_now, 0);
+                    c0 = c1 + 1;
+                }
+                ingest(A, 1, rows_now, (uint32_t)instances.size());
+                SHP_HIP(hipStreamWaitEvent(st, pr->ev2, 0));
+            } else {
+                ingest(0, A + 1, rows_now, (uint32_t)instances.size());
+                if (early_lookups) early_err = lookup_columns(Fr::zero(), st);
             }
+            if (early_lookups) jobs[n_jobs++] = MsmJob{srs->msm_gl, V(I_PIN), n, 2 * L, MsmRows{n, 0, 0}, pts.data() + A};
             pr->msm_ws.poll_results = true;
             msm_launch_jobs(jobs, n_jobs, pr->msm_ws, st);
             msm_finish_jobs(pr->msm_ws_rand, st);
@@ -1338,7 +1461,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             ingest(0, A + 2, rows_now, (uint32_t)instances.size());
             rand_values();
             if (early_lookups) {
-                early_err = lookup_columns(Fr::zero());
+                early_err = lookup_columns(Fr::zero(), st);
                 jobs[n_jobs++] = MsmJob{srs->msm_gl, V(I_PIN), n, 2 * L, MsmRows{n, 0, 0}, pts.data() + A};
             }
             jobs[n_jobs++] = MsmJob{srs->msm_gl, rand_lag, n, 1, MsmRows{n, 0, 0}, &rand_comm};
@@ -1443,7 +1566,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     pc.mark("advice_msm");
     // ---- P3: lookups -- compress, permute, commit (unless their columns went out with the advice columns' launch)
     if (L && !early_lookups) {
-        uint32_t* const herr = lookup_columns(theta);
+        uint32_t* const herr = lookup_columns(theta, st);
         if (split_commits) {
             commit_launch(pr->msm_ws, srs->msm_gl, V(I_PIN), 2 * L, pts.data());
             msm_finish_jobs(pr->msm_ws, st);
