@@ -786,6 +786,17 @@ struct shp_prover {
     // polynomial's commitment.  Empty ranges: the plan does not allow it (see early_lookup_ops).
     hipStream_t st2 = nullptr;
     hipEvent_t ev2 = nullptr;
+    // The coefficient forms and cosets of the columns that are final when the advice commitment is launched, on the second
+    // stream while the first one commits and builds the grand products (a lone proof): ev_cols = those columns are on the
+    // device, ev_tr = their cosets are.  ntt_tmp2 is that stream's transform scratch.
+    hipEvent_t ev_cols = nullptr, ev_tr = nullptr;
+    Fr* ntt_tmp2 = nullptr;
+    void second_stream() {                         // created on first use: pool lanes never need it
+        if (!st2) SHP_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));   // default priority
+        if (!ev2) SHP_HIP(hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
+        if (!ev_cols) SHP_HIP(hipEventCreateWithFlags(&ev_cols, hipEventDisableTiming));
+        if (!ev_tr) SHP_HIP(hipEventCreateWithFlags(&ev_tr, hipEventDisableTiming));
+    }
     std::vector<WitnessSchedule::Range> early_ranges;
     std::vector<uint32_t> early_cols;
     bool throughput = false;               // shp_prover_mode(1): scheduling choices of a pool lane
@@ -808,6 +819,8 @@ struct shp_prover {
     ~shp_prover() {
         if (comb_event) (void)hipEventDestroy(comb_event);
         if (ev2) (void)hipEventDestroy(ev2);
+        if (ev_cols) (void)hipEventDestroy(ev_cols);
+        if (ev_tr) (void)hipEventDestroy(ev_tr);
         if (st2) (void)hipStreamDestroy(st2);
         stage.release();
         h_rand.release();
@@ -868,6 +881,9 @@ static void early_lookup_ops(const PlanData& P, std::vector<WitnessSchedule::Ran
     }
     for (uint32_t c = 0; c < A; c++)
         if (is_col[c]) cols.push_back(c);
+    if (getenv("SHP_PHASE_TRACE"))
+        fprintf(stderr, "[witness] ahead of the program: %zu of %zu ops in %zu runs feed the lookups' %zu columns\n", kept,
+                P.wops.size(), ranges.size(), cols.size());
 }
 
 static void set_witness_threads(shp_prover* pr, uint32_t threads) {
@@ -936,10 +952,7 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->msm_ws.poll_results = poll_results_enabled();       // a new lane is a latency lane until shp_prover_mode says otherwise
     pr->wscratch.assign(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
     early_lookup_ops(P, pr->early_ranges, pr->early_cols);
-    if (!pr->early_ranges.empty()) {
-        SHP_HIP(hipStreamCreateWithFlags(&pr->st2, hipStreamNonBlocking));
-        SHP_HIP(hipEventCreateWithFlags(&pr->ev2, hipEventDisableTiming));
-    }
+    if (!pr->early_ranges.empty()) pr->second_stream();
     if (P.phased()) {
         const size_t cnt = P.consts.size() + P.challenge_phase.size();
         pr->consts_lane = pr->dalloc<Fr>(cnt);
@@ -1196,6 +1209,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     NttOpts ntt_ext;                                     // values on the nc cosets of the quotient domain
     ntt_ext.twist = pk->twist; ntt_ext.twist_count = pk->nc;
     uint32_t inv_done = 0, ext_done = 0;                 // columns [0, inv_done) have coefficients, [0, ext_done) cosets
+    bool transforms_ahead = false;                       // ... the leading ones of them on the second stream (ev_tr)
     auto inv_upto = [&](uint32_t c) {
         if (c <= inv_done) return;
         ntt_launch(ctx, pr->vals + (size_t)inv_done * n, pr->polys + (size_t)inv_done * n, k, c - inv_done, ntt_inv, st, pr->ntt_tmp);
@@ -1452,7 +1466,25 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             }
             if (early_lookups) jobs[n_jobs++] = MsmJob{srs->msm_gl, V(I_PIN), n, 2 * L, MsmRows{n, 0, 0}, pts.data() + A};
             pr->msm_ws.poll_results = true;
+            // every column in front of the grand products is final now: its coefficient form and cosets (P9) are computed on
+            // the second stream, next to this commitment and the grand products, instead of behind them
+            static const bool tr_ahead_on = !(getenv("SHP_TRANSFORMS_AHEAD") && atoi(getenv("SHP_TRANSFORMS_AHEAD")) == 0);
+            const uint32_t final_cols = (early_lookups || L == 0) ? I_PZ : A;
+            const bool tr_ahead = tr_ahead_on && final_cols > 0;
+            if (tr_ahead) {
+                pr->second_stream();
+                SHP_HIP(hipEventRecord(pr->ev_cols, st));
+            }
             msm_launch_jobs(jobs, n_jobs, pr->msm_ws, st);
+            if (tr_ahead) {
+                if (!pr->ntt_tmp2) pr->ntt_tmp2 = pr->dalloc<Fr>((size_t)I_PZ * ne);
+                SHP_HIP(hipStreamWaitEvent(pr->st2, pr->ev_cols, 0));
+                ntt_launch(ctx, pr->vals, pr->polys, k, final_cols, ntt_inv, pr->st2, pr->ntt_tmp2);
+                ntt_launch(ctx, pr->polys, pr->cos, k, final_cols * pk->nc, ntt_ext, pr->st2, pr->ntt_tmp2);
+                SHP_HIP(hipEventRecord(pr->ev_tr, pr->st2));
+                inv_done = ext_done = final_cols;
+                transforms_ahead = true;
+            }
             msm_finish_jobs(pr->msm_ws_rand, st);
             msm_finish_jobs(pr->msm_ws, st);
         } else {
@@ -1619,7 +1651,10 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     ctr += 1;
     // ---- P9 (coefficient forms and cosets of everything committed so far + the instance column) needs no challenge: for
     // a lone proof it is queued behind the grand products' commitment and runs while the host waits for those points
-    auto transforms = [&] { ext_upto(NV + 1); };
+    auto transforms = [&] {
+        ext_upto(NV + 1);
+        if (transforms_ahead) SHP_HIP(hipStreamWaitEvent(st, pr->ev_tr, 0));
+    };
     if (split_commits && S + L) {
         commit_launch(pr->msm_ws, srs->msm_gl, V(I_PZ), S + L, pts.data());
         transforms();
