@@ -741,7 +741,7 @@ constexpr uint32_t C29_POINT_WORDS = 36 * COOP_SLOTS;         // [4 coords][9 li
 constexpr uint32_t C29_SCR_WORDS = 9 * 9 * 64;                // [9 values][9 limbs][64 quads]
 constexpr uint32_t C29_LDS_WORDS = C29_POINT_WORDS + C29_SCR_WORDS + 64 + COOP_SLOTS;
 
-__device__ __forceinline__ G1X29 block_sum_256_29(G1X29 acc, uint32_t* sh /* [C29_LDS_WORDS] */) {
+__device__ __forceinline__ G1X29 block_sum_256_29(G1X29 acc, uint32_t* sh /* [C29_LDS_WORDS] */, uint32_t count = MSM_THREADS) {
     const uint32_t t = threadIdx.x;
     uint32_t* scr = sh + C29_POINT_WORDS;
     uint32_t* flg = scr + C29_SCR_WORDS;                        // per quad: bit0 inf1, bit1 inf2, bit2 same x (maybe)
@@ -776,17 +776,24 @@ __device__ __forceinline__ G1X29 block_sum_256_29(G1X29 acc, uint32_t* sh /* [C2
         p.inf = infl[slot] != 0;
         return p;
     };
-    if (t >= 128) put(t - 128, acc);
-    __syncthreads();
-    if (t < 128) {
-        acc = g1_add29(acc, get(t));
+    // `count` (wave-uniform): threads >= count are known to hold the identity
+    if (count > 128) {
+        if (t >= 128) put(t - 128, acc);
+        __syncthreads();
+        if (t < 128) {
+            acc = g1_add29(acc, get(t));
+            put(t, acc);
+        }
+    } else if (t < 128) {
         put(t, acc);
     }
     __syncthreads();
+    uint32_t m0 = 64;
+    while (m0 > 1 && m0 >= count) m0 >>= 1;               // slots >= count hold the identity: nothing to add there
     enum { V_U1 = 0, V_S1, V_U2, V_S2, V_PPU, V_PP, V_RR, V_RR2, V_PPP };
     const uint32_t q = t >> 2, j = t & 3;
     const Fq29 zero29 = {};
-    for (uint32_t m = 64; m >= 1; m >>= 1) {
+    for (uint32_t m = m0; m >= 1; m >>= 1) {
         const bool act = t < 4 * m;
         const bool wave_act = (t & ~63u) < 4 * m;               // a wave with no lane in the level skips the products
         const uint32_t a = q, b = q + m;
@@ -880,7 +887,6 @@ __device__ __forceinline__ G1X29 block_sum_256_29(G1X29 acc, uint32_t* sh /* [C2
 template <bool LAZY29>
 __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a) {
     __shared__ uint32_t sh[LAZY29 ? C29_LDS_WORDS : COOP_LDS_WORDS];
-    static_assert(C29_LDS_WORDS >= COOP_LDS_WORDS, "the final merge of the partial sums uses the 8 x 32-bit tree");
     uint32_t lo = 0, hi = a.n_segs;                            // last segment with wg_base <= blockIdx.x
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -943,30 +949,38 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
             }
         }
     }
-    if constexpr (LAZY29) {
-        const G1X29 sum29 = block_sum_256_29(acc29, sh);
-        if (threadIdx.x == 0) acc = to_g1x(sum29);
-    } else {
-        acc = block_sum_256(acc, sh);
-    }
+    if constexpr (LAZY29) acc29 = block_sum_256_29(acc29, sh);
+    else acc = block_sum_256(acc, sh);
     // The workgroup that stores the last partial sum of an MSM adds them all up: no second dispatch (on a busy chip a
     // dispatch costs its stream tens of microseconds whatever its size).  Device-scope fences on both sides of the
     // count make the partials of workgroups on other XCDs (other L2s) visible to the one that reads them.
     __shared__ uint32_t is_last;
     const uint32_t P = sg.gx * gridDim.y;
     uint32_t* const done = a.done + sg.msm_base + m;
+    // (the lazy form keeps its partial sums lazy: they are converted once, after the merge)
+    G1X29* const partials29 = reinterpret_cast<G1X29*>(a.partials);
     if (threadIdx.x == 0) {
-        a.partials[part] = acc;
+        if constexpr (LAZY29) partials29[part] = acc29;
+        else a.partials[part] = acc;
         __threadfence();
         is_last = atomicAdd(done, 1u) + 1 == P;
     }
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    const G1X* p = a.partials + sg.part_base + (size_t)m * P;
     G1X sum = G1X::inf();
-    for (uint32_t j = threadIdx.x; j < P; j += MSM_THREADS) sum = g1_add(sum, p[j]);
-    sum = block_sum_256(sum, sh, P < MSM_THREADS ? P : MSM_THREADS);
+    if constexpr (LAZY29) {
+        const G1X29* p = partials29 + sg.part_base + (size_t)m * P;
+        G1X29 sum29;
+        sum29.inf = true;
+        for (uint32_t j = threadIdx.x; j < P; j += MSM_THREADS) sum29 = g1_add29(sum29, p[j]);
+        sum29 = block_sum_256_29(sum29, sh, P < MSM_THREADS ? P : MSM_THREADS);
+        if (threadIdx.x == 0) sum = to_g1x(sum29);
+    } else {
+        const G1X* p = a.partials + sg.part_base + (size_t)m * P;
+        for (uint32_t j = threadIdx.x; j < P; j += MSM_THREADS) sum = g1_add(sum, p[j]);
+        sum = block_sum_256(sum, sh, P < MSM_THREADS ? P : MSM_THREADS);
+    }
     if (threadIdx.x == 0) {
         a.out[sg.msm_base + m] = sum;
         *done = 0;                                             // ready for the next launch
@@ -1192,7 +1206,7 @@ void msm_launch_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace
         segs[k].part_base = parts;
         parts += (uint64_t)jobs[k].batch * segs[k].gx * gy;
     }
-    ws.pf.reserve(parts * sizeof(G1X));
+    ws.pf.reserve(parts * std::max(sizeof(G1X), sizeof(G1X29)));   // (the lazy kernel stores its partial sums in its own form)
     ws.h_out.reserve(total * sizeof(G1X));                     // before the launch: the final sums are written
     ws.done.reserve(std::max<size_t>(total, 256) * sizeof(uint32_t));
     if (ws.done_zeroed != ws.done.cap) {                       // grown (or new): the counters start at zero, and every
