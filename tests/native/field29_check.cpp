@@ -2,6 +2,7 @@
 // Exit code 0 and a line "ok ..." when every comparison holds; the first mismatch is printed and the exit code is 1.
 #include <stdio.h>
 #include <stdlib.h>
+#include <initializer_list>
 #include "../../zkos-monorepo_amd/csrc/field29.hip.hpp"
 
 using namespace shp;
@@ -111,6 +112,45 @@ int main(int argc, char** argv) {
         G1X29 got2 = g1_add29(got, a29);
         if (!same_point(to_g1x(got2), want2)) { printf("add29 (second level) mismatch: case %d kind %d\n", it, (int)kind); return 1; }
     }
+    // 3b. projective points with the complete addition: trees of partial sums with the exceptional cases spliced in, and the
+    // coordinates pushed towards their bound (4.5 p) by adding multiples of p
+    long padds = 0;
+    auto lift = [&](Fq29& v, int times) {
+        for (int e = 0; e < times; e++) {
+            for (int i = 0; i < 9; i++) v.l[i] += f29::P29.l[i];
+            normalise29(v);
+        }
+    };
+    for (int it = 0; it < rounds / 4 + 1; it++) {
+        G1X ra = G1X::inf(), rb = G1X::inf();
+        G1X29 a29, b29;
+        a29.inf = true; b29.inf = true;
+        const int la = (int)(rnd() % 6), lb = (int)(rnd() % 6);
+        for (int s = 0; s < la; s++) { const G1Affine q = pts[rnd() % n_pts]; ra = g1_madd(ra, q.x, q.y); g1_madd29(a29, q.x, q.y); }
+        for (int s = 0; s < lb; s++) { const G1Affine q = pts[rnd() % n_pts]; rb = g1_madd(rb, q.x, q.y); g1_madd29(b29, q.x, q.y); }
+        const uint64_t kind = rnd() % 8;
+        if (kind == 0) { rb = ra; b29 = a29; }
+        if (kind == 1) { rb = ra.negated(); b29 = from_g1x(rb); }
+        if (kind == 2 && !ra.is_inf()) { rb = G1X::from_affine(g1_to_affine(ra)); b29 = from_g1x(rb); }
+        G1P29 pa = g1p_from_x29(a29), pb = g1p_from_x29(b29);
+        if (!same_point(g1p_to_g1x(pa), ra)) { printf("projective conversion mismatch: case %d\n", it); return 1; }
+        lift(pa.x, (int)(rnd() % 4)); lift(pa.y, (int)(rnd() % 4)); lift(pa.z, (int)(rnd() % 2));      // < 4.5 p each
+        lift(pb.x, (int)(rnd() % 4)); lift(pb.y, (int)(rnd() % 4)); lift(pb.z, (int)(rnd() % 2));
+        const G1X want = g1_add(ra, rb);
+        const G1P29 got = g1p_add29(pa, pb);
+        padds++;
+        if (!same_point(g1p_to_g1x(got), want)) { printf("projective add mismatch: case %d kind %d\n", it, (int)kind); return 1; }
+        // sums of sums, the sum with itself, and the sum with its opposite
+        const G1P29 got2 = g1p_add29(got, pa), dbl = g1p_add29(got, got);
+        if (!same_point(g1p_to_g1x(got2), g1_add(want, ra))) { printf("projective add (second level) mismatch: case %d\n", it); return 1; }
+        if (!same_point(g1p_to_g1x(dbl), g1_add(want, want))) { printf("projective doubling mismatch: case %d\n", it); return 1; }
+        const G1P29 neg = g1p_from_x29(from_g1x(want.negated()));
+        if (!g1p_to_g1x(g1p_add29(got, neg)).is_inf()) { printf("projective P + (-P) mismatch: case %d\n", it); return 1; }
+        // coordinates stay below 4.5 p: the top limb of 4.5 p
+        for (const Fq29* c : {&got2.x, &got2.y, &got2.z})
+            if (c->l[8] > (uint32_t)((9ull * (f29::P29.l[8] + 1)) / 2)) { printf("projective bound exceeded: case %d\n", it); return 1; }
+        padds += 4;
+    }
     // 4. the same arithmetic over Fr (the quotient kernels): products, squares, subtractions, both conversions
     using LR = Lazy29<FrParams>;
     constexpr l29::L9 RKP3 = LR::kp_spread(3), RKP40 = LR::kp_spread(40, 2);
@@ -130,6 +170,6 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 9; i++) bb.l[i] = a29.l[i] + b29.l[i];                 // < 33.1 p, limbs < 2^30
         if (LR::to_fp(LR::sub(b29, bb, RKP40)) != b - (a + b)) { printf("Fr wide sub mismatch at %d\n", it); return 1; }
     }
-    printf("ok %d products, %ld additions, %ld general additions\n", rounds, adds, gadds);
+    printf("ok %d products, %ld additions, %ld general additions, %ld projective additions\n", rounds, adds, gadds, padds);
     return 0;
 }

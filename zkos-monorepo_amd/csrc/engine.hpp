@@ -80,6 +80,9 @@ struct MsmWorkspace {
     // direct mode, a lone proof's lane: wait for the sums themselves (stamps in pinned memory) instead of the stream
     bool poll_results = false;
     PinnedBuf h_stamp;
+    PinnedBuf h_trace;                     // SHP_MSM_TRACE=1: the kernel's clock readings of the launch in flight
+    uint64_t trace_wgs = 0;
+    uint32_t trace_msms = 0;
     uint32_t stamp_seq = 0;
     // the launch in flight between msm_launch_jobs and msm_finish_jobs
     struct PendJob { G1Affine* h_out; uint32_t msm_base, batch; };
@@ -90,6 +93,7 @@ struct MsmWorkspace {
         cnt.release(); start.release(); entries.release(); pf.release(); pl.release(); buckets.release(); out.release();
         wg_hist.release(); binned.release(); cursor.release(); h_out.release(); h_totals.release(); segs.release(); h_segs.release(); seg_cached = 0;
         h_stamp.release();
+        h_trace.release();
         done.release(); done_zeroed = 0;
     }
 };

@@ -575,6 +575,9 @@ struct DirectArgs {
     G1X* out;             // per MSM: the sum (may be pinned host memory)
     uint32_t* stamp;      // per MSM, pinned host memory (null: none): set to `seq` once the sum is stored (wait_stamps)
     uint32_t seq;
+    // diagnostics (SHP_MSM_TRACE=1, else null): per workgroup the constant-rate clock at its start, after its lanes' sums,
+    // after its tree; then, behind those, the clock when the last workgroup starts and ends the merge of each MSM
+    uint64_t* trace;
 };
 
 // Sum of one XYZZ point per thread over a 256-thread workgroup; the result is valid in thread 0.
@@ -733,152 +736,107 @@ __device__ __forceinline__ G1X block_sum_256(G1X acc, uint32_t* sh /* [COOP_LDS_
     return r;
 }
 
-// The same sum over accumulators in the 29-bit lazy form (field29.hip.hpp): 226 instructions per product instead of ~330,
-// and the 256 accumulators of a workgroup are not converted back to the 8 x 32-bit form first (four products each) --
-// only the one sum is.  Same rounds, same lanes; every value keeps the accumulator bounds of g1_add29.  Slots carry an
-// identity flag of their own (a lazy zz has no canonical zero).
-constexpr uint32_t C29_POINT_WORDS = 36 * COOP_SLOTS;         // [4 coords][9 limbs][128 slots]
-constexpr uint32_t C29_SCR_WORDS = 9 * 9 * 64;                // [9 values][9 limbs][64 quads]
-constexpr uint32_t C29_LDS_WORDS = C29_POINT_WORDS + C29_SCR_WORDS + 64 + COOP_SLOTS;
+// Sum of one projective point per thread (field29.hip.hpp: G1P29, complete addition) over a 256-thread workgroup; the result is
+// valid in thread 0.  SIX lanes share an addition: round 1 is one product per lane, the six products go through LDS to the
+// lanes of the group, each forms its two operands of round 2 (linear in the six), round 2 is again one product per lane,
+// and the even lanes combine their product with their neighbour's into a coordinate of the sum.  Two product rounds and two
+// barriers per pass instead of the four and five of the XYZZ addition, and no exceptional cases.  A wave holds ten groups
+// (lanes 60..63 idle), a workgroup forty: a pass adds the last min(40, n / 2) live points onto the first ones, 256 points
+// take eleven passes.
+constexpr uint32_t RCB_PITCH = 272;                           // slots per limb row: 9 * 272 = 16 (mod 64), so the three
+                                                              // coordinates of a slot sit in different banks
+constexpr uint32_t RCB_GROUPS_PER_WAVE = 10, RCB_GROUPS = 4 * RCB_GROUPS_PER_WAVE;
+constexpr uint32_t RCB_POINT_WORDS = 27 * RCB_PITCH;          // [3 coords][9 limbs][slots]
+constexpr uint32_t RCB_SCR_WORDS = 9 * MSM_THREADS;           // [9 limbs][thread]: a round's products, then 9 X1 X2 likewise
+constexpr uint32_t RCB_LDS_WORDS = RCB_POINT_WORDS + 2 * RCB_SCR_WORDS;
 
-__device__ __forceinline__ G1X29 block_sum_256_29(G1X29 acc, uint32_t* sh /* [C29_LDS_WORDS] */, uint32_t count = MSM_THREADS) {
+// `count` (workgroup-uniform, >= 1): threads >= count hold nothing (their point is ignored)
+__device__ __forceinline__ G1P29 block_sum_rcb29(const G1P29& mine, uint32_t* sh /* [RCB_LDS_WORDS] */, uint32_t count = MSM_THREADS) {
     const uint32_t t = threadIdx.x;
-    uint32_t* scr = sh + C29_POINT_WORDS;
-    uint32_t* flg = scr + C29_SCR_WORDS;                        // per quad: bit0 inf1, bit1 inf2, bit2 same x (maybe)
-    uint32_t* infl = flg + 64;                                  // per slot: the point is the identity
+    uint32_t* const scr = sh + RCB_POINT_WORDS;
     auto ldc = [&](uint32_t coord, uint32_t slot) {
         Fq29 v;
 #pragma unroll
-        for (int i = 0; i < 9; i++) v.l[i] = sh[(coord * 9 + i) * COOP_SLOTS + slot];
+        for (int i = 0; i < 9; i++) v.l[i] = sh[(coord * 9 + i) * RCB_PITCH + slot];
         return v;
     };
     auto stc = [&](uint32_t coord, uint32_t slot, const Fq29& v) {
 #pragma unroll
-        for (int i = 0; i < 9; i++) sh[(coord * 9 + i) * COOP_SLOTS + slot] = v.l[i];
+        for (int i = 0; i < 9; i++) sh[(coord * 9 + i) * RCB_PITCH + slot] = v.l[i];
     };
-    auto lds = [&](uint32_t val, uint32_t quad) {
+    auto lds = [&](uint32_t at) {                              // a value of the scratch rows: limb i at scr[at + 256 i]
         Fq29 v;
 #pragma unroll
-        for (int i = 0; i < 9; i++) v.l[i] = scr[(val * 9 + i) * 64 + quad];
+        for (int i = 0; i < 9; i++) v.l[i] = scr[at + i * MSM_THREADS];
         return v;
     };
-    auto sts = [&](uint32_t val, uint32_t quad, const Fq29& v) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) scr[(val * 9 + i) * 64 + quad] = v.l[i];
-    };
-    auto put = [&](uint32_t slot, const G1X29& p) {
-        stc(0, slot, p.x); stc(1, slot, p.y); stc(2, slot, p.zz); stc(3, slot, p.zzz);
-        infl[slot] = p.inf ? 1u : 0u;
-    };
-    auto get = [&](uint32_t slot) {
-        G1X29 p;
-        p.x = ldc(0, slot); p.y = ldc(1, slot); p.zz = ldc(2, slot); p.zzz = ldc(3, slot);
-        p.inf = infl[slot] != 0;
-        return p;
-    };
-    // `count` (wave-uniform): threads >= count are known to hold the identity
-    if (count > 128) {
-        if (t >= 128) put(t - 128, acc);
-        __syncthreads();
-        if (t < 128) {
-            acc = g1_add29(acc, get(t));
-            put(t, acc);
-        }
-    } else if (t < 128) {
-        put(t, acc);
-    }
+    if (t < count) { stc(0, t, mine.x); stc(1, t, mine.y); stc(2, t, mine.z); }
     __syncthreads();
-    uint32_t m0 = 64;
-    while (m0 > 1 && m0 >= count) m0 >>= 1;               // slots >= count hold the identity: nothing to add there
-    enum { V_U1 = 0, V_S1, V_U2, V_S2, V_PPU, V_PP, V_RR, V_RR2, V_PPP };
-    const uint32_t q = t >> 2, j = t & 3;
-    const Fq29 zero29 = {};
-    for (uint32_t m = m0; m >= 1; m >>= 1) {
-        const bool act = t < 4 * m;
-        const bool wave_act = (t & ~63u) < 4 * m;               // a wave with no lane in the level skips the products
-        const uint32_t a = q, b = q + m;
-        Fq29 mine = zero29, keep = zero29;
-        // R1: u1 = x1 zz2 | s1 = y1 zzz2 | u2 = x2 zz1 | s2 = y2 zzz1
-        Fq29 A1 = zero29, B1 = zero29;
-        if (act) {
-            A1 = ldc(j & 1, (j & 2) ? b : a);
-            B1 = ldc(2 + (j & 1), (j & 2) ? a : b);
-        }
-        if (wave_act) mine = mul29(A1, B1);
-        if (act) sts(V_U1 + j, q, mine);
-        __syncthreads();
-        // R2: pp = (u2 - u1)^2 | rr2 = (s2 - s1)^2 | zz12 | zzz12
-        Fq29 A2 = zero29, B2 = zero29;
-        if (act) {
-            if (j < 2) {
-                A2 = sub29(lds(V_U2 + j, q), mine, f29::KP3);    // < 5.5 p
-                B2 = A2;
-                sts(j == 0 ? V_PPU : V_RR, q, A2);
-                if (j == 0)
-                    flg[q] = (infl[a] ? 1u : 0u) | (infl[b] ? 2u : 0u) | ((((A2.l[0] * f29::PPOSINV29) & M29) < 6u) ? 4u : 0u);
-            } else {
-                A2 = ldc(j, a);
-                B2 = ldc(j, b);
-            }
-        }
-        if (wave_act) keep = mul29(A2, B2);
-        if (act && j < 2) sts(j == 0 ? V_PP : V_RR2, q, keep);
-        __syncthreads();
-        // R3: qq = u1 pp | - | zz3 = zz12 pp | ppp = (u2 - u1) pp
-        Fq29 A3 = zero29, B3 = zero29;
-        if (act) {
-            B3 = lds(V_PP, q);
-            A3 = j == 0 ? mine : keep;
-            if (j == 3) A3 = lds(V_PPU, q);
-        }
-        Fq29 r3 = zero29;
-        if (wave_act) r3 = mul29(A3, B3);
-        if (act && j == 3) sts(V_PPP, q, r3);
-        __syncthreads();
-        // R4: x3 = rr2 - ppp - 2 qq, t2 = rr (qq - x3) | t1 = s1 ppp | - | zzz3 = zzz12 ppp
-        Fq29 A4 = zero29, B4 = zero29, out = r3;                  // lane 2: zz3
-        if (act) {
-            if (j == 0) {
-                const Fq29 rr2 = lds(V_RR2, q), ppp = lds(V_PPP, q);
-#pragma unroll
-                for (int i = 0; i < 9; i++) out.l[i] = rr2.l[i] + f29::KP8W.l[i] - ppp.l[i] - (r3.l[i] << 1);
-                normalise29(out);                                 // x3 < 10.5 p
-                A4 = lds(V_RR, q);
-#pragma unroll
-                for (int i = 0; i < 9; i++) B4.l[i] = r3.l[i] + f29::KP11.l[i] - out.l[i];   // qq - x3 + 11 p, one lazy operand
-            } else if (j == 1) {
-                A4 = mine;                                        // s1
-                B4 = lds(V_PPP, q);
-            } else if (j == 3) {
-                A4 = keep;                                        // zzz12
-                B4 = r3;                                          // ppp
-            }
-        }
-        Fq29 r4 = zero29;
-        if (wave_act) r4 = mul29(A4, B4);                         // t2 | t1 | - | zzz3
-        if (act && j == 0) sts(V_U2, q, r4);
-        if (j == 3) out = r4;
-        __syncthreads();
-        // R5: y3, select around identities, write the sum into slot a
-        bool special = false;
-        if (act) {
-            const uint32_t f = flg[q];
-            if (j == 1) out = sub29(lds(V_U2, q), r4, f29::KP3);  // y3 = t2 - t1 < 5.5 p
-            if (f & 1u) {                                         // P = O: the sum is Q
-                stc(j, a, ldc(j, b));
-                if (j == 0) infl[a] = (f >> 1) & 1u;
-            } else if (f & 2u) {                                  // Q = O: the sum is P, already in slot a
-            } else if (f & 4u) special = true;                    // same x (or a chance hit): exact arithmetic
-            else stc(j, a, out);
-        }
-        if (__syncthreads_or(special ? 1 : 0)) {
-            if (act && j == 0 && special) put(a, g1_add29(get(a), get(b)));
-            __syncthreads();
-        }
+    const uint32_t lane = t & 63, wave = t >> 6;
+    const uint32_t gl = lane / 6, j = lane - 6 * gl;           // group of the wave, lane of the group
+    const uint32_t g = wave * RCB_GROUPS_PER_WAVE + gl;
+    const uint32_t base = t - j;                               // the group's products of a round: scr[base + 0..5 + 256 i]
+    // round 1, lane j: X1 X2 | Y1 Y2 | Zs1 Zs2 | (X1+Y1)(X2+Y2) | (Y1+Zs1)(Y2+Zs2) | (X1+Zs1)(X2+Zs2)
+    const uint32_t c0 = (j == 1 || j == 4) ? 1u : j == 2 ? 2u : 0u;
+    const uint32_t c1 = j == 3 ? 1u : 2u;
+    const uint32_t pair_mask = j >= 3 ? ~0u : 0u;
+    // round 2, lane j: t3 d | t4 t5 | d s | x9 t5 | s t4 | x9 t3, each operand  a - b - c + 3 p  or  a + c + 3 p  over the
+    // round-1 products V0..V5 (scratch row offsets 0..5) and x9 (second scratch block): {a, b, c} offsets and masks
+    enum : uint32_t { V0 = 0, V1, V2, V3, V4, V5, X9 = RCB_SCR_WORDS, MB = 1, MC = 2, MP = 4 };
+    uint32_t aA, bA, cA, fA, aB, bB, cB, fB;
+    switch (j) {
+        case 0:  aA = V3; bA = V0; cA = V1; fA = MB | MC;      aB = V1; bB = V2; cB = V2; fB = MB;           break;   // t3, d
+        case 1:  aA = V4; bA = V1; cA = V2; fA = MB | MC;      aB = V5; bB = V0; cB = V2; fB = MB | MC;      break;   // t4, t5
+        case 2:  aA = V1; bA = V2; cA = V2; fA = MB;           aB = V1; bB = V2; cB = V2; fB = MC | MP;      break;   // d, s
+        case 3:  aA = X9; bA = V0; cA = V0; fA = 0;            aB = V5; bB = V0; cB = V2; fB = MB | MC;      break;   // x9, t5
+        case 4:  aA = V1; bA = V2; cA = V2; fA = MC | MP;      aB = V4; bB = V1; cB = V2; fB = MB | MC;      break;   // s, t4
+        default: aA = X9; bA = V0; cA = V0; fA = 0;            aB = V3; bB = V0; cB = V1; fB = MB | MC;      break;   // x9, t3
     }
-    G1X29 r;
-    r.inf = true;
-    if (t == 0) r = get(0);
+    aA += base; bA += base; cA += base; aB += base; bB += base; cB += base;
+    const uint32_t mbA = 0u - (fA & 1u), mcA = 0u - ((fA >> 1) & 1u), mpA = 0u - ((fA >> 2) & 1u);
+    const uint32_t mbB = 0u - (fB & 1u), mcB = 0u - ((fB >> 1) & 1u), mpB = 0u - ((fB >> 2) & 1u);
+    const Fq29 zero29 = {};
+    uint32_t n = count;
+    while (n > 1) {
+        const uint32_t adds = n / 2 < RCB_GROUPS ? n / 2 : RCB_GROUPS;
+        const bool act = gl < RCB_GROUPS_PER_WAVE && g < adds;
+        const bool wave_act = wave * RCB_GROUPS_PER_WAVE < adds;   // a wave with no group in the pass only meets the barriers
+        const uint32_t a = g, b = n - adds + g;                // slot b is added onto slot a
+        if (wave_act) {
+            Fq29 u = zero29, v = zero29;
+            if (act) {
+                u = rcb_pair(ldc(c0, a), ldc(c1, a), pair_mask);
+                v = rcb_pair(ldc(c0, b), ldc(c1, b), pair_mask);
+            }
+            const Fq29 p1 = mul29(u, v);
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) scr[t + i * MSM_THREADS] = p1.l[i];
+                if (j == 0) {
+                    const Fq29 x9 = rcb_times9(p1);
+#pragma unroll
+                    for (int i = 0; i < 9; i++) scr[RCB_SCR_WORDS + t + i * MSM_THREADS] = x9.l[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (wave_act) {
+            Fq29 A = zero29, B = zero29;
+            if (act) {
+                A = rcb_lin(lds(aA), lds(bA), mbA, lds(cA), mcA, mpA);
+                B = rcb_lin(lds(aB), lds(bB), mbB, lds(cB), mcB, mpB);
+            }
+            const Fq29 p2 = mul29(A, B);
+            Fq29 nb;                                           // the neighbour's product (lane + 1: same group for even j)
+#pragma unroll
+            for (int i = 0; i < 9; i++) nb.l[i] = __shfl_down(p2.l[i], 1);
+            if (act && !(j & 1)) stc(j >> 1, a, rcb_out(p2, nb, j == 0));
+        }
+        __syncthreads();
+        n -= adds;
+    }
+    G1P29 r = g1p_identity();
+    if (t == 0) { r.x = ldc(0, 0); r.y = ldc(1, 0); r.z = ldc(2, 0); }
     return r;
 }
 
@@ -886,13 +844,15 @@ __device__ __forceinline__ G1X29 block_sum_256_29(G1X29 acc, uint32_t* sh /* [C2
 // only row blocks a segment visits are launched (an empty workgroup still costs ~0.1 us of dispatch)
 template <bool LAZY29>
 __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a) {
-    __shared__ uint32_t sh[LAZY29 ? C29_LDS_WORDS : COOP_LDS_WORDS];
+    __shared__ uint32_t sh[LAZY29 ? RCB_LDS_WORDS : COOP_LDS_WORDS];
     uint32_t lo = 0, hi = a.n_segs;                            // last segment with wg_base <= blockIdx.x
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (a.segs[mid].wg_base <= blockIdx.x) lo = mid; else hi = mid;
     }
     const DirectSeg sg = a.segs[lo];
+    const uint32_t wg_id = blockIdx.y * gridDim.x + blockIdx.x;
+    if (a.trace && threadIdx.x == 0) a.trace[3 * (size_t)wg_id] = wall_clock64();
     const uint32_t bx = blockIdx.x - sg.wg_base;
     const uint32_t m = bx / sg.gx, blk = bx % sg.gx;
     const uint32_t lane = blk * MSM_THREADS + threadIdx.x;
@@ -949,18 +909,24 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
             }
         }
     }
-    if constexpr (LAZY29) acc29 = block_sum_256_29(acc29, sh);
+    if (a.trace) {
+        __syncthreads();
+        if (threadIdx.x == 0) a.trace[3 * (size_t)wg_id + 1] = wall_clock64();
+    }
+    G1P29 accp;
+    if constexpr (LAZY29) accp = block_sum_rcb29(g1p_from_x29(acc29), sh);
     else acc = block_sum_256(acc, sh);
+    if (a.trace && threadIdx.x == 0) a.trace[3 * (size_t)wg_id + 2] = wall_clock64();
     // The workgroup that stores the last partial sum of an MSM adds them all up: no second dispatch (on a busy chip a
     // dispatch costs its stream tens of microseconds whatever its size).  Device-scope fences on both sides of the
     // count make the partials of workgroups on other XCDs (other L2s) visible to the one that reads them.
     __shared__ uint32_t is_last;
     const uint32_t P = sg.gx * gridDim.y;
     uint32_t* const done = a.done + sg.msm_base + m;
-    // (the lazy form keeps its partial sums lazy: they are converted once, after the merge)
-    G1X29* const partials29 = reinterpret_cast<G1X29*>(a.partials);
+    // (the lazy form keeps its partial sums lazy and projective: they are converted once, after the merge)
+    G1P29* const partials29 = reinterpret_cast<G1P29*>(a.partials);
     if (threadIdx.x == 0) {
-        if constexpr (LAZY29) partials29[part] = acc29;
+        if constexpr (LAZY29) partials29[part] = accp;
         else a.partials[part] = acc;
         __threadfence();
         is_last = atomicAdd(done, 1u) + 1 == P;
@@ -968,14 +934,18 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
     __syncthreads();
     if (!is_last) return;
     __threadfence();
+    uint64_t* const trace_merge = a.trace ? a.trace + 3 * (size_t)gridDim.x * gridDim.y + 2 * (size_t)(sg.msm_base + m) : nullptr;
+    if (trace_merge && threadIdx.x == 0) trace_merge[0] = wall_clock64();
     G1X sum = G1X::inf();
     if constexpr (LAZY29) {
-        const G1X29* p = partials29 + sg.part_base + (size_t)m * P;
-        G1X29 sum29;
-        sum29.inf = true;
-        for (uint32_t j = threadIdx.x; j < P; j += MSM_THREADS) sum29 = g1_add29(sum29, p[j]);
-        sum29 = block_sum_256_29(sum29, sh, P < MSM_THREADS ? P : MSM_THREADS);
-        if (threadIdx.x == 0) sum = to_g1x(sum29);
+        const G1P29* p = partials29 + sg.part_base + (size_t)m * P;
+        G1P29 sump = g1p_identity();
+        if (threadIdx.x < P) {
+            sump = p[threadIdx.x];
+            for (uint32_t j = threadIdx.x + MSM_THREADS; j < P; j += MSM_THREADS) sump = g1p_add29(sump, p[j]);
+        }
+        sump = block_sum_rcb29(sump, sh, P < MSM_THREADS ? P : MSM_THREADS);
+        if (threadIdx.x == 0) sum = g1p_to_g1x(sump);
     } else {
         const G1X* p = a.partials + sg.part_base + (size_t)m * P;
         for (uint32_t j = threadIdx.x; j < P; j += MSM_THREADS) sum = g1_add(sum, p[j]);
@@ -984,6 +954,7 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
     if (threadIdx.x == 0) {
         a.out[sg.msm_base + m] = sum;
         *done = 0;                                             // ready for the next launch
+        if (trace_merge) trace_merge[1] = wall_clock64();
         if (a.stamp) publish_stamp(a.stamp + sg.msm_base + m, a.seq);
     }
 }
@@ -1206,7 +1177,7 @@ void msm_launch_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace
         segs[k].part_base = parts;
         parts += (uint64_t)jobs[k].batch * segs[k].gx * gy;
     }
-    ws.pf.reserve(parts * std::max(sizeof(G1X), sizeof(G1X29)));   // (the lazy kernel stores its partial sums in its own form)
+    ws.pf.reserve(parts * std::max(sizeof(G1X), sizeof(G1P29)));   // (the lazy kernel stores its partial sums in its own form)
     ws.h_out.reserve(total * sizeof(G1X));                     // before the launch: the final sums are written
     ws.done.reserve(std::max<size_t>(total, 256) * sizeof(uint32_t));
     if (ws.done_zeroed != ws.done.cap) {                       // grown (or new): the counters start at zero, and every
@@ -1248,6 +1219,15 @@ void msm_launch_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace
     const bool poll = ws.poll_results && !tm->enabled;         // (event timing needs the stream drained)
     a.stamp = nullptr;
     a.seq = 0;
+    a.trace = nullptr;
+    static const bool trace_on = getenv("SHP_MSM_TRACE") && atoi(getenv("SHP_MSM_TRACE")) != 0;
+    if (trace_on) {
+        ws.trace_wgs = busy_wgs * gy;
+        ws.trace_msms = total;
+        ws.h_trace.reserve((3 * ws.trace_wgs + 2 * total) * sizeof(uint64_t));
+        memset(ws.h_trace.p, 0, (3 * ws.trace_wgs + 2 * total) * sizeof(uint64_t));
+        a.trace = ws.h_trace.as<uint64_t>();
+    }
     if (poll) {
         ws.h_stamp.reserve(std::max<size_t>(total, 64) * sizeof(uint32_t));
         a.stamp = ws.h_stamp.as<uint32_t>();
@@ -1276,6 +1256,27 @@ void msm_finish_jobs(shp::MsmWorkspace& ws, hipStream_t st) {
     if (ws.pend_poll) shp::wait_stamps(ws.h_stamp.as<uint32_t>(), total, ws.pend_seq, st);
     else shp::sync_stream(st);
     if (ws.timers) ws.timers->collect();
+    if (ws.trace_wgs) {                                            // SHP_MSM_TRACE: where a launch's time goes
+        shp::sync_stream(st);
+        const uint64_t* t = ws.h_trace.as<uint64_t>();
+        const uint64_t* mg = t + 3 * ws.trace_wgs;
+        uint64_t t0 = ~0ull, start_max = 0, sums_max = 0, tree_max = 0, merge0 = 0, merge1 = 0;
+        for (uint64_t w = 0; w < ws.trace_wgs; w++) t0 = std::min(t0, t[3 * w]);
+        for (uint64_t w = 0; w < ws.trace_wgs; w++) {
+            start_max = std::max(start_max, t[3 * w] - t0);
+            sums_max = std::max(sums_max, t[3 * w + 1] - t0);
+            tree_max = std::max(tree_max, t[3 * w + 2] - t0);
+        }
+        for (uint32_t i = 0; i < ws.trace_msms; i++) {
+            merge0 = std::max(merge0, mg[2 * i] - t0);
+            merge1 = std::max(merge1, mg[2 * i + 1] - t0);
+        }
+        // the clock runs at 100 MHz
+        fprintf(stderr, "[msm] %llu workgroups, %u sums: last start %.1f us, lanes' sums done %.1f, trees done %.1f, merge %.1f -> %.1f\n",
+                (unsigned long long)ws.trace_wgs, ws.trace_msms, start_max / 100.0, sums_max / 100.0, tree_max / 100.0,
+                merge0 / 100.0, merge1 / 100.0);
+        ws.trace_wgs = 0;
+    }
     ws.h_aff.resize(total);
     normalise_batch(ws.h_out.as<G1X>(), total, ws.h_aff.data());
     for (const auto& pj : ws.pend) memcpy(pj.h_out, ws.h_aff.data() + pj.msm_base, (size_t)pj.batch * sizeof(G1Affine));
