@@ -796,9 +796,20 @@ __device__ __forceinline__ G1P29 block_sum_rcb29(const G1P29& mine, uint32_t* sh
     const uint32_t mbA = 0u - (fA & 1u), mcA = 0u - ((fA >> 1) & 1u), mpA = 0u - ((fA >> 2) & 1u);
     const uint32_t mbB = 0u - (fB & 1u), mcB = 0u - ((fB >> 1) & 1u), mpB = 0u - ((fB >> 2) & 1u);
     const Fq29 zero29 = {};
+    // A group never spans two waves, so what its lanes exchange inside a pass needs no workgroup barrier: the LDS executes a
+    // wave's instructions in order, the fence keeps the compiler from moving them across.
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     uint32_t n = count;
     while (n > 1) {
         const uint32_t adds = n / 2 < RCB_GROUPS ? n / 2 : RCB_GROUPS;
+        // from ten additions down (a pass never has more than the one before) the first wave works alone: the others leave,
+        // and it needs no workgroup barrier any more (the one that ended the previous pass made their sums visible)
+        const bool solo = adds <= RCB_GROUPS_PER_WAVE;
+        if (solo && wave != 0) break;
         const bool act = gl < RCB_GROUPS_PER_WAVE && g < adds;
         const bool wave_act = wave * RCB_GROUPS_PER_WAVE < adds;   // a wave with no group in the pass only meets the barriers
         const uint32_t a = g, b = n - adds + g;                // slot b is added onto slot a
@@ -819,7 +830,7 @@ __device__ __forceinline__ G1P29 block_sum_rcb29(const G1P29& mine, uint32_t* sh
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         if (wave_act) {
             Fq29 A = zero29, B = zero29;
             if (act) {
@@ -832,7 +843,7 @@ __device__ __forceinline__ G1P29 block_sum_rcb29(const G1P29& mine, uint32_t* sh
             for (int i = 0; i < 9; i++) nb.l[i] = __shfl_down(p2.l[i], 1);
             if (act && !(j & 1)) stc(j >> 1, a, rcb_out(p2, nb, j == 0));
         }
-        __syncthreads();
+        if (solo) wave_sync(); else __syncthreads();
         n -= adds;
     }
     G1P29 r = g1p_identity();
