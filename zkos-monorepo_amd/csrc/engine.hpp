@@ -89,6 +89,7 @@ struct MsmWorkspace {
     std::vector<PendJob> pend;
     uint32_t pend_total = 0, pend_seq = 0;
     bool pend_poll = false;
+    bool pend_projective = false;          // its sums are lazy projective points (field29.hip.hpp: G1P29), not XYZZ
     void release() {
         cnt.release(); start.release(); entries.release(); pf.release(); pl.release(); buckets.release(); out.release();
         wg_hist.release(); binned.release(); cursor.release(); h_out.release(); h_totals.release(); segs.release(); h_segs.release(); seg_cached = 0;

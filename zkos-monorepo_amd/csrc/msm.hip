@@ -576,7 +576,8 @@ struct DirectArgs {
     uint32_t* stamp;      // per MSM, pinned host memory (null: none): set to `seq` once the sum is stored (wait_stamps)
     uint32_t seq;
     // diagnostics (SHP_MSM_TRACE=1, else null): per workgroup the constant-rate clock at its start, after its lanes' sums,
-    // after its tree; then, behind those, the clock when the last workgroup starts and ends the merge of each MSM
+    // after its tree; then, behind those, per MSM the clock when the last workgroup starts the merge, has the sum, has
+    // converted it and has stored it
     uint64_t* trace;
 };
 
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    uint64_t* const trace_merge = a.trace ? a.trace + 3 * (size_t)gridDim.x * gridDim.y + 2 * (size_t)(sg.msm_base + m) : nullptr;
+    uint64_t* const trace_merge = a.trace ? a.trace + 3 * (size_t)gridDim.x * gridDim.y + 4 * (size_t)(sg.msm_base + m) : nullptr;
     if (trace_merge && threadIdx.x == 0) trace_merge[0] = wall_clock64();
     G1X sum = G1X::inf();
     if constexpr (LAZY29) {
@@ -956,16 +957,24 @@ __global__ __launch_bounds__(MSM_THREADS, 2) void msm_direct_kernel(DirectArgs a
             for (uint32_t j = threadIdx.x + MSM_THREADS; j < P; j += MSM_THREADS) sump = g1p_add29(sump, p[j]);
         }
         sump = block_sum_rcb29(sump, sh, P < MSM_THREADS ? P : MSM_THREADS);
-        if (threadIdx.x == 0) sum = g1p_to_g1x(sump);
+        if (threadIdx.x == 0) {
+            // the sum leaves as it is (lazy, projective): the host, which divides by Z anyway, converts it in a fraction
+            // of the eight products that one lane here would spend on it
+            if (trace_merge) trace_merge[1] = trace_merge[2] = wall_clock64();
+            reinterpret_cast<G1P29*>(a.out)[sg.msm_base + m] = sump;
+        }
     } else {
         const G1X* p = a.partials + sg.part_base + (size_t)m * P;
         for (uint32_t j = threadIdx.x; j < P; j += MSM_THREADS) sum = g1_add(sum, p[j]);
         sum = block_sum_256(sum, sh, P < MSM_THREADS ? P : MSM_THREADS);
     }
     if (threadIdx.x == 0) {
-        a.out[sg.msm_base + m] = sum;
+        if constexpr (!LAZY29) {
+            if (trace_merge) trace_merge[1] = trace_merge[2] = wall_clock64();
+            a.out[sg.msm_base + m] = sum;
+        }
         *done = 0;                                             // ready for the next launch
-        if (trace_merge) trace_merge[1] = wall_clock64();
+        if (trace_merge) trace_merge[3] = wall_clock64();
         if (a.stamp) publish_stamp(a.stamp + sg.msm_base + m, a.seq);
     }
 }
@@ -1131,6 +1140,26 @@ static void normalise_batch(const G1X* in, uint32_t batch, G1Affine* h_out) {
     }
 }
 
+// the same for the lazy projective sums (X : Y : 3 Z) of the direct kernel: x = 3 X / Zs, y = 3 Y / Zs
+static void normalise_batch_p29(const G1P29* in, uint32_t batch, G1Affine* h_out) {
+    std::vector<Fq> pre(batch), zs(batch);
+    Fq acc = Fq::one();
+    for (uint32_t b = 0; b < batch; b++) {
+        zs[b] = to_fq(in[b].z);                                // canonical: zero exactly for the identity
+        pre[b] = acc;
+        if (!zs[b].is_zero()) acc = acc * zs[b];
+    }
+    Fq inv = Fq::inv(acc);
+    for (uint32_t b = batch; b-- > 0;) {
+        if (zs[b].is_zero()) { h_out[b].x = Fq::zero(); h_out[b].y = Fq::zero(); continue; }
+        const Fq zi = inv * pre[b];
+        inv = inv * zs[b];
+        const Fq zi3 = zi + zi + zi;
+        h_out[b].x = to_fq(in[b].x) * zi3;
+        h_out[b].y = to_fq(in[b].y) * zi3;
+    }
+}
+
 // All jobs in ONE launch of msm_direct_kernel (the final sums included), in two halves so that a caller can queue other
 // work behind the launch before it waits: msm_launch_jobs returns once the kernel is queued, msm_finish_jobs waits for the
 // sums -- for their stamps in pinned memory when the workspace polls (whatever else the stream still holds), for the
@@ -1235,8 +1264,8 @@ void msm_launch_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace
     if (trace_on) {
         ws.trace_wgs = busy_wgs * gy;
         ws.trace_msms = total;
-        ws.h_trace.reserve((3 * ws.trace_wgs + 2 * total) * sizeof(uint64_t));
-        memset(ws.h_trace.p, 0, (3 * ws.trace_wgs + 2 * total) * sizeof(uint64_t));
+        ws.h_trace.reserve((3 * ws.trace_wgs + 4 * total) * sizeof(uint64_t));
+        memset(ws.h_trace.p, 0, (3 * ws.trace_wgs + 4 * total) * sizeof(uint64_t));
         a.trace = ws.h_trace.as<uint64_t>();
     }
     if (poll) {
@@ -1256,6 +1285,7 @@ void msm_launch_jobs(const shp::MsmJob* jobs, uint32_t n_jobs, shp::MsmWorkspace
     ws.pend_total = (uint32_t)total;
     ws.pend_poll = poll;
     ws.pend_seq = a.seq;
+    ws.pend_projective = lazy29;
     ws.last_adds = visited_all * W;                           // upper bound: one mixed add per non-zero digit
     ws.last_bytes = visited_all * 32 + (uint64_t)m0->n * 64;
 }
@@ -1271,7 +1301,7 @@ void msm_finish_jobs(shp::MsmWorkspace& ws, hipStream_t st) {
         shp::sync_stream(st);
         const uint64_t* t = ws.h_trace.as<uint64_t>();
         const uint64_t* mg = t + 3 * ws.trace_wgs;
-        uint64_t t0 = ~0ull, start_max = 0, sums_max = 0, tree_max = 0, merge0 = 0, merge1 = 0;
+        uint64_t t0 = ~0ull, start_max = 0, sums_max = 0, tree_max = 0, merge0 = 0, merge1 = 0, merge2 = 0, merge3 = 0;
         for (uint64_t w = 0; w < ws.trace_wgs; w++) t0 = std::min(t0, t[3 * w]);
         for (uint64_t w = 0; w < ws.trace_wgs; w++) {
             start_max = std::max(start_max, t[3 * w] - t0);
@@ -1279,17 +1309,20 @@ void msm_finish_jobs(shp::MsmWorkspace& ws, hipStream_t st) {
             tree_max = std::max(tree_max, t[3 * w + 2] - t0);
         }
         for (uint32_t i = 0; i < ws.trace_msms; i++) {
-            merge0 = std::max(merge0, mg[2 * i] - t0);
-            merge1 = std::max(merge1, mg[2 * i + 1] - t0);
+            merge0 = std::max(merge0, mg[4 * i] - t0);
+            merge1 = std::max(merge1, mg[4 * i + 1] - t0);
+            merge2 = std::max(merge2, mg[4 * i + 2] - t0);
+            merge3 = std::max(merge3, mg[4 * i + 3] - t0);
         }
         // the clock runs at 100 MHz
-        fprintf(stderr, "[msm] %llu workgroups, %u sums: last start %.1f us, lanes' sums done %.1f, trees done %.1f, merge %.1f -> %.1f\n",
+        fprintf(stderr, "[msm] %llu workgroups, %u sums: last start %.1f us, lanes' sums done %.1f, trees done %.1f, merge %.1f -> sum %.1f -> converted %.1f -> stored %.1f\n",
                 (unsigned long long)ws.trace_wgs, ws.trace_msms, start_max / 100.0, sums_max / 100.0, tree_max / 100.0,
-                merge0 / 100.0, merge1 / 100.0);
+                merge0 / 100.0, merge1 / 100.0, merge2 / 100.0, merge3 / 100.0);
         ws.trace_wgs = 0;
     }
     ws.h_aff.resize(total);
-    normalise_batch(ws.h_out.as<G1X>(), total, ws.h_aff.data());
+    if (ws.pend_projective) normalise_batch_p29(ws.h_out.as<G1P29>(), total, ws.h_aff.data());
+    else normalise_batch(ws.h_out.as<G1X>(), total, ws.h_aff.data());
     for (const auto& pj : ws.pend) memcpy(pj.h_out, ws.h_aff.data() + pj.msm_base, (size_t)pj.batch * sizeof(G1Affine));
 }
 
