@@ -796,7 +796,6 @@ __device__ __forceinline__ G1P29 block_sum_rcb29(const G1P29& mine, uint32_t* sh
     aA += base; bA += base; cA += base; aB += base; bB += base; cB += base;
     const uint32_t mbA = 0u - (fA & 1u), mcA = 0u - ((fA >> 1) & 1u), mpA = 0u - ((fA >> 2) & 1u);
     const uint32_t mbB = 0u - (fB & 1u), mcB = 0u - ((fB >> 1) & 1u), mpB = 0u - ((fB >> 2) & 1u);
-    const Fq29 zero29 = {};
     // A group never spans two waves, so what its lanes exchange inside a pass needs no workgroup barrier: the LDS executes a
     // wave's instructions in order, the fence keeps the compiler from moving them across.
     auto wave_sync = [] {
@@ -815,11 +814,10 @@ __device__ __forceinline__ G1P29 block_sum_rcb29(const G1P29& mine, uint32_t* sh
         const bool wave_act = wave * RCB_GROUPS_PER_WAVE < adds;   // a wave with no group in the pass only meets the barriers
         const uint32_t a = g, b = n - adds + g;                // slot b is added onto slot a
         if (wave_act) {
-            Fq29 u = zero29, v = zero29;
-            if (act) {
-                u = rcb_pair(ldc(c0, a), ldc(c1, a), pair_mask);
-                v = rcb_pair(ldc(c0, b), ldc(c1, b), pair_mask);
-            }
+            // (a lane with no addition in this pass reads slots of the shared array all the same -- b stays below 296 --
+            // and multiplies what it finds: cheaper than selecting zeros, and it stores nothing)
+            const Fq29 u = rcb_pair(ldc(c0, a), ldc(c1, a), pair_mask);
+            const Fq29 v = rcb_pair(ldc(c0, b), ldc(c1, b), pair_mask);
             const Fq29 p1 = mul29(u, v);
             if (act) {
 #pragma unroll
@@ -833,11 +831,8 @@ __device__ __forceinline__ G1P29 block_sum_rcb29(const G1P29& mine, uint32_t* sh
         }
         wave_sync();
         if (wave_act) {
-            Fq29 A = zero29, B = zero29;
-            if (act) {
-                A = rcb_lin(lds(aA), lds(bA), mbA, lds(cA), mcA, mpA);
-                B = rcb_lin(lds(aB), lds(bB), mbB, lds(cB), mcB, mpB);
-            }
+            const Fq29 A = rcb_lin(lds(aA), lds(bA), mbA, lds(cA), mcA, mpA);
+            const Fq29 B = rcb_lin(lds(aB), lds(bB), mbB, lds(cB), mcB, mpB);
             const Fq29 p2 = mul29(A, B);
             Fq29 nb;                                           // the neighbour's product (lane + 1: same group for even j)
 #pragma unroll

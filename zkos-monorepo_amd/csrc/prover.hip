@@ -1112,7 +1112,8 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     // host_points (with diff_points): the same points on the host.  Then nobody waits for the total: the product of
     // omega^r - p over the whole domain is p^n - 1 (n even), which the host has inverted before the kernel starts.
     auto product_scans = [&](const Fr* a, const Fr* b, uint32_t cnt, const Fr* diff_points = nullptr,
-                             const Fr* host_points = nullptr) -> InvList {
+                             const Fr* host_points = nullptr, hipStream_t on = nullptr) -> InvList {
+        hipStream_t st = on ? on : pr->st;                // (shadows the lane's stream: a caller may name another one)
         InvList il;
         il.n = 0;
         const bool closed_form = diff_points && host_points && cnt <= INV_LIST_MAX && n >= 2;
@@ -1125,8 +1126,11 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         T.stamp = poll ? (uint32_t*)pr->stage_alloc(cnt * sizeof(uint32_t)) : nullptr;
         T.seq = poll ? (++pr->stamp_seq ? pr->stamp_seq : ++pr->stamp_seq) : 0;
         for (uint32_t i = 0; poll && i < cnt; i++) T.stamp[i] = T.seq - 1;
-        hipLaunchKernelGGL(sce == 1 ? scan_local_kernel<1> : scan_local_kernel<SCAN_E_POOL>, dim3(snb, cnt), dim3(sbs), 0, st, a, b,
-                           n, pr->sc_pre, pr->sc_suf, sc_ta, sc_tb, T);
+        if (sce == 1 && snb <= 64 && sbs >= 128)            // a lone proof: one direction per workgroup, half the chain (two waves scan the totals)
+            hipLaunchKernelGGL(scan_split_kernel, dim3(snb, cnt, 2), dim3(sbs), 0, st, a, b, n, pr->sc_pre, pr->sc_suf, sc_ta, sc_tb, T);
+        else
+            hipLaunchKernelGGL(sce == 1 ? scan_local_kernel<1> : scan_local_kernel<SCAN_E_POOL>, dim3(snb, cnt), dim3(sbs), 0, st, a,
+                               b, n, pr->sc_pre, pr->sc_suf, sc_ta, sc_tb, T);
         if (closed_form) {
             il.n = cnt;
             for (uint32_t i = 0; i < cnt; i++) {
@@ -1143,9 +1147,10 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         return il;
     };
     // out[p][r] = 1 / (omega^r - points[p])
-    auto invert_point_diffs = [&](const Fr* points, const Fr* host_points, Fr* out, uint32_t cnt) {
+    auto invert_point_diffs = [&](const Fr* points, const Fr* host_points, Fr* out, uint32_t cnt, hipStream_t on = nullptr) {
+        hipStream_t st = on ? on : pr->st;
         pr->timers.begin(KID_BATCH_INVERT, st);
-        const InvList il = product_scans(nullptr, nullptr, cnt, points, host_points);
+        const InvList il = product_scans(nullptr, nullptr, cnt, points, host_points, st);
         hipLaunchKernelGGL(sce == 1 ? batch_invert_apply_kernel<1> : batch_invert_apply_kernel<SCAN_E_POOL>, dim3(snb, cnt),
                            dim3(sbs), 0, st, (const Fr*)nullptr, pk->omegas, points, pr->sc_pre, pr->sc_suf, sc_bpre, sc_bsuf,
                            sc_inv, n, out, il);
@@ -1451,15 +1456,10 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         if (split_commits) {
             // witness rows and instances in one dispatch; the random polynomial is on its way already
             if (lookups_ahead) {
-                // every column but those that went ahead (they are being read on the second stream), then the instances
-                uint32_t c0 = 0;
-                for (size_t k0 = 0; k0 <= pr->early_cols.size(); k0++) {
-                    const uint32_t c1 = k0 < pr->early_cols.size() ? pr->early_cols[k0] : A;
-                    if (c1 > c0) ingest(c0, c1 - c0, rows_now, 0);
-                    c0 = c1 + 1;
-                }
-                ingest(A, 1, rows_now, (uint32_t)instances.size());
+                // behind the second stream's work (long done by now): the columns that went ahead are simply uploaded again
+                // with the others, one dispatch for all
                 SHP_HIP(hipStreamWaitEvent(st, pr->ev2, 0));
+                ingest(0, A + 1, rows_now, (uint32_t)instances.size());
             } else {
                 ingest(0, A + 1, rows_now, (uint32_t)instances.size());
                 if (early_lookups) early_err = lookup_columns(Fr::zero(), st);
@@ -1839,7 +1839,8 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     // (the values of hx and of the random polynomial on the domain, which the evaluation-form opening reads, exist already:
     // lag2 from the powers launch above, rand_lag from the random polynomial's commitment)
     // 1 / (omega^r - point) for every opening point: it depends on x alone, so it is queued here, behind the evaluations,
-    // and runs while the host hashes them and prepares the opening argument
+    // and runs while the host hashes them and prepares the opening argument.  (On the second stream, next to the
+    // evaluations, it gained nothing: the extra event and launch calls cost the host what the overlap saved.)
     invert_point_diffs(d_points, points.data(), pr->dinv, (uint32_t)points.size());
     if (poll_evals) wait_stamps(eval_stamp, (uint32_t)jobs.size(), eval_seq, st);
     else sync_stream(st);

@@ -407,6 +407,74 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_local_kernel(const Fr* a, c
     if (t == 0 && T.total_out && T.stamp) publish_stamp(T.stamp + blockIdx.y, T.seq);
 }
 
+// The same scans for a lone proof (one element per thread, nb <= 64 blocks of >= 128 threads), ONE DIRECTION PER WORKGROUP: grid (nb, cnt, 2),
+// z = 0 the prefix products of a, z = 1 the suffix products of b.  A lane of scan_local_kernel multiplies twice per step
+// (its prefix and its suffix); here the two chains run side by side on different workgroups -- ten dependent products
+// before the block totals are out instead of twenty-one -- and the workgroup that stores a product's last total scans the
+// totals on two waves, one per direction.
+__global__ __launch_bounds__(SCAN_THREADS) void scan_split_kernel(const Fr* a, const Fr* b, uint32_t n, Fr* pre_a, Fr* suf_b,
+                                                                  Fr* tot_a, Fr* tot_b, ScanTotals T) {
+    __shared__ Fr wv[SCAN_THREADS / 64];
+    __shared__ uint32_t is_last;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, bs = blockDim.x, nw = (bs + 63) >> 6;
+    const uint32_t wl = bs < 64 ? bs : 64;                 // lanes of a wave that hold a thread
+    const uint32_t slot = blockIdx.x * bs + t, p = blockIdx.y, nb = gridDim.x;
+    const bool fwd = blockIdx.z == 0;
+    Fr v;
+    if (T.omegas) v = ld(T.omegas + slot) - ld(T.points + p);
+    else v = ld((fwd ? a : b) + (size_t)p * n + slot);
+    // inclusive scan inside the wave, towards higher lanes (prefix) or lower ones (suffix)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Fr o = fwd ? shfl_up_fr(v, off) : shfl_down_fr(v, off);
+        if (fwd ? (int)lane >= off : lane + off < wl) v = v * o;
+    }
+    if (lane == (fwd ? wl - 1 : 0)) wv[wave] = v;
+    __syncthreads();
+    // the waves before (after) this one, then the thread's inclusive product over the workgroup
+    Fr carry = Fr::one();
+    bool any = false;
+    for (uint32_t w = 0; w < nw; w++) {
+        if (fwd ? w < wave : w > wave) {
+            carry = any ? carry * wv[w] : wv[w];
+            any = true;
+        }
+    }
+    if (any) v = v * carry;
+    Fr ex = fwd ? shfl_up_fr(v, 1) : shfl_down_fr(v, 1);  // exclusive
+    if (lane == (fwd ? 0 : wl - 1)) ex = carry;
+    st((fwd ? pre_a : suf_b) + (size_t)p * n + slot, ex);
+    if (t == (fwd ? bs - 1 : 0)) {                         // this thread's inclusive product is the workgroup's total
+        st((fwd ? tot_a : tot_b) + (size_t)p * nb + blockIdx.x, v);
+        __threadfence();
+        is_last = atomicAdd(T.done + p, 1u) + 1 == 2 * nb;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (t == 0) T.done[p] = 0;
+    if (t >= 128) return;
+    // totals: wave 0 the exclusive prefixes of tot_a, wave 1 the exclusive suffixes of tot_b and the product of all b
+    const bool tf = wave == 0;
+    Fr x = lane < nb ? ld((tf ? tot_a : tot_b) + (size_t)p * nb + lane) : Fr::one();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Fr o = tf ? shfl_up_fr(x, off) : shfl_down_fr(x, off);
+        if (tf ? (int)lane >= off : lane + off < 64) x = x * o;
+    }
+    Fr e = tf ? shfl_up_fr(x, 1) : shfl_down_fr(x, 1);
+    if (lane == (tf ? 0u : 63u)) e = Fr::one();
+    if (lane < nb) st((tf ? T.bpre_a : T.bsuf_b) + (size_t)p * nb + lane, e);
+    if (!tf && lane == 0) {                                // lane 0's inclusive suffix = the product of all b
+        if (T.total_out) {
+            st(T.total_out + p, x);
+            if (T.stamp) publish_stamp(T.stamp + p, T.seq);
+        } else {
+            st(T.inv_b + p, Fr::inv(x));
+        }
+    }
+}
+
 // The threads of one workgroup (256, or fewer when the product has one block) for product p, nb <= 256 block totals.
 // bpre_a[k] = prod_{j<k} tot_a[j]; bsuf_b[k] = prod_{j>k} tot_b[j]; inv_b = 1 / prod_j tot_b[j]
 // total_out (pinned host memory) non-null: the product of all b goes there instead of its inverse into inv_b --
