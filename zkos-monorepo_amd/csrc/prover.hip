@@ -1477,7 +1477,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             }
             msm_launch_jobs(jobs, n_jobs, pr->msm_ws, st);
             if (tr_ahead) {
-                if (!pr->ntt_tmp2) pr->ntt_tmp2 = pr->dalloc<Fr>((size_t)I_PZ * ne);
+                if (!pr->ntt_tmp2) pr->ntt_tmp2 = pr->dalloc<Fr>((size_t)(NV + 1) * ne);
                 SHP_HIP(hipStreamWaitEvent(pr->st2, pr->ev_cols, 0));
                 ntt_launch(ctx, pr->vals, pr->polys, k, final_cols, ntt_inv, pr->st2, pr->ntt_tmp2);
                 ntt_launch(ctx, pr->polys, pr->cos, k, final_cols * pk->nc, ntt_ext, pr->st2, pr->ntt_tmp2);
@@ -1651,11 +1651,23 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     ctr += 1;
     // ---- P9 (coefficient forms and cosets of everything committed so far + the instance column) needs no challenge: for
     // a lone proof it is queued behind the grand products' commitment and runs while the host waits for those points
+    // (with the leading columns' transforms on the second stream, the rest -- the grand products and the instance column
+    // -- follow them there, next to the grand products' commitment instead of behind it)
     auto transforms = [&] {
+        if (transforms_ahead) {
+            const uint32_t c0 = ext_done, cnt = NV + 1 - ext_done;
+            SHP_HIP(hipStreamWaitEvent(pr->st2, pr->ev_cols, 0));
+            ntt_launch(ctx, pr->vals + (size_t)c0 * n, pr->polys + (size_t)c0 * n, k, cnt, ntt_inv, pr->st2, pr->ntt_tmp2);
+            ntt_launch(ctx, pr->polys + (size_t)c0 * n, pr->cos + (size_t)c0 * ne, k, cnt * pk->nc, ntt_ext, pr->st2, pr->ntt_tmp2);
+            SHP_HIP(hipEventRecord(pr->ev_tr, pr->st2));
+            inv_done = ext_done = NV + 1;
+            SHP_HIP(hipStreamWaitEvent(st, pr->ev_tr, 0));
+            return;
+        }
         ext_upto(NV + 1);
-        if (transforms_ahead) SHP_HIP(hipStreamWaitEvent(st, pr->ev_tr, 0));
     };
     if (split_commits && S + L) {
+        if (transforms_ahead) SHP_HIP(hipEventRecord(pr->ev_cols, st));   // the grand products are on the device
         commit_launch(pr->msm_ws, srs->msm_gl, V(I_PZ), S + L, pts.data());
         transforms();
         msm_finish_jobs(pr->msm_ws, st);
