@@ -952,7 +952,8 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->msm_ws.poll_results = poll_results_enabled();       // a new lane is a latency lane until shp_prover_mode says otherwise
     pr->wscratch.assign(std::max<uint32_t>(P.n_wscratch, 1), Fr::zero());
     early_lookup_ops(P, pr->early_ranges, pr->early_cols);
-    if (!pr->early_ranges.empty()) pr->second_stream();
+    // (no second stream yet: a pool lane never uses one, and every stream a process creates shifts the mapping of the
+    // lanes' streams onto the hardware queues -- one idle stream per lane cost the pool 5 % and the interpreted plans 20 %)
     if (P.phased()) {
         const size_t cnt = P.consts.size() + P.challenge_phase.size();
         pr->consts_lane = pr->dalloc<Fr>(cnt);
@@ -1405,6 +1406,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
                 ~Joiner() { join(); }
             } started;
             if (ahead) {
+                pr->second_stream();
                 for (const auto& r : pr->early_ranges) run_witness_range(P, inputs, grid, pr->wscratch.data(), r.lo, r.hi);
                 for (uint32_t c : pr->early_cols)
                     for (uint32_t r = u; r < n; r++) grid[(size_t)c * n + r] = blind_of(c, r);
