@@ -355,8 +355,9 @@ def test_merkle_tree_matches_contract_semantics(shp, oracle, gpu_ctx):
 
 
 def test_msm_direct_tree_special_cases(shp, oracle, gpu_ctx):
-    """the cooperative tree additions of the direct-table MSM: equal partial sums (doubling), opposite
-    partial sums (cancel to the identity), identities scattered among the lanes"""
+    """the reduction trees of the direct-table MSM (six lanes an addition, complete formulas: no exceptional cases to
+    branch on): equal partial sums (doubling), opposite partial sums (cancel to the identity, at the first passes and at
+    the last one), identities scattered among the lanes"""
     n = 4096
     osrs = oracle.srs_synthetic(12, 0xDEADBEEFCAFE1234567)
     bases = osrs.g.copy()
@@ -378,4 +379,24 @@ def test_msm_direct_tree_special_cases(shp, oracle, gpu_ctx):
     for i, c in enumerate(cols):
         assert np.array_equal(got[i], oracle.msm(bases, s_arr.reshape(len(cols), n, 4)[i])), f"column {i}"
     assert not got[1].any() and not got[4].any()   # everything cancels
+    m.close()
+
+
+def test_msm_direct_more_partial_sums_than_threads(shp, oracle, gpu_ctx, monkeypatch):
+    """2^17 bases through a direct table (35 GB at the budget set here): 512 row blocks, so the workgroup that merges an
+    MSM's partial sums holds two of them per thread before its tree starts (one lane's complete addition); columns of
+    random scalars, of one repeated scalar, and one whose second half cancels the first"""
+    monkeypatch.setenv("SHP_MSM_TABLE_GB", "40")
+    n = 1 << 17
+    osrs = oracle.srs_synthetic(13, 24680)
+    bases = np.tile(osrs.g, (n // osrs.n, 1))
+    m = shp.Msm(gpu_ctx, bases)
+    rnd = random.Random(17)
+    half = [rnd.randrange(1, R) for _ in range(n // 2)]
+    cols = [None, [7] * n, half + [R - x for x in half]]      # bases repeat with period 8192: column 2 sums to the identity
+    s = np.concatenate([rand_fr(oracle, n, 4711), oracle.fr_array(cols[1]), oracle.fr_array(cols[2])])
+    got = m.run(shp.to_device(s), n, 3)
+    for i in range(3):
+        assert np.array_equal(got[i], oracle.msm(bases, s.reshape(3, n, 4)[i])), f"column {i}"
+    assert not got[2].any()
     m.close()
