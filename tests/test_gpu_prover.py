@@ -107,6 +107,9 @@ def test_error_paths(shp, oracle, gpu_ctx):
     with pytest.raises(shp.ShpError) as e:
         tpr.prove([99, 99], bytes(32))
     assert e.value.code == 6
+    # the refused proof left transforms in flight on the prover's second stream: the next proof is unaffected
+    proof2, inst2 = tpr.prove([7, 7], bytes(32))
+    assert proof2 == oproof and inst2 == inst
     tpr.close(); tpk.close(); tparams.close()
 
 
