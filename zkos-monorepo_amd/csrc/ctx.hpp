@@ -72,6 +72,9 @@ struct NttOpts {
     // with coefficient i scaled by twist[(b % twist_count) * 2^log_n + i] (= c_j^i: values on the coset c_j * H)
     const Fr* twist = nullptr;
     uint32_t twist_count = 0;
+    // output i of transform b scaled by out_table[b * 2^log_n + i] INSTEAD of the inverse transform's 1/n (the table
+    // carries that factor): the product the final store spends on 1/n anyway does a second job
+    const Fr* out_table = nullptr;
 };
 // `tmp`: caller-owned ping-pong buffer of batch * 2^log_n elements (needed when log_n > 11);
 // nullptr = the context's shared buffer (single-stream use only)

@@ -48,6 +48,7 @@ struct PassParams {
     Fr scale, zeta, zeta2;
     const Fr* twist;          // first pass only (null: none)
     uint32_t src_div;         // first pass: transforms per input polynomial (>= 1)
+    const Fr* out_table;      // final pass only (null: none): per-output factors [transform][2^log_n], in place of `scale`
 };
 
 __device__ __forceinline__ Fr lds_load(const uint4* lo, const uint4* hi, uint32_t i) {
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
         } else {
             uint32_t k1 = k1_base | v;
             go = (size_t)k1 + ((size_t)k2 << p.s1) + ((size_t)kp << (p.s1 + p.s2));
-            if (p.do_scale) val = val * p.scale;
+            if (p.out_table) val = val * gload(p.out_table + ((size_t)blockIdx.y << p.log_n) + go);
+            else if (p.do_scale) val = val * p.scale;
             if (p.post_pattern) {
                 uint32_t m = (uint32_t)(go % 3);
                 if (m == 1) val = val * p.zeta2;
@@ -611,6 +613,7 @@ static void ntt_launch_with(shp_ctx* ctx, const NttTables& T, uint32_t tw_shift,
         p.zeta2 = ctx->zeta2;
         p.twist = o.twist;
         p.src_div = o.twist && o.twist_count ? o.twist_count : 1;
+        p.out_table = p.is_final ? o.out_table : nullptr;
         p.small_tw = ctx->ntt_small[dir];
         p.tw_lo = T.lo[dir];
         p.tw_hi = T.hi[dir];
@@ -620,7 +623,7 @@ static void ntt_launch_with(shp_ctx* ctx, const NttTables& T, uint32_t tw_shift,
         if (p.is_final) { p.dst = d_out; p.dst_stride = N; }
         else { p.dst = tmp; p.dst_stride = N; }
         uint32_t tiles = (uint32_t)(N >> (p.s + p.c));
-        if (ntt29_mode()) {
+        if (ntt29_mode() && !o.out_table) {               // (the 29-bit tile has no per-output table)
             Pass29 q;
             q.small_a = ctx->ntt_small29_a[dir];
             q.small_b = ctx->ntt_small29_b[dir];

@@ -80,11 +80,11 @@ struct shp_pk {
     // The quotient domain: the quotient has degree < (d - 1) n, so nc = d - 1 cosets c_j * H of size n carry it,
     // c_j = zeta * omega_ext^j -- a subset of halo2's extended domain zeta * H_ext (2^e n points), laid out
     // coset-major: index j * n + t <-> point c_j * omega^t.  nq = nc * n (7 n instead of 8 n for the withdraw
-    // circuit).  twist[j][i] = c_j^i turns coefficients into values on coset j with one size-n NTT; cinv[j][t] =
-    // c_j^-t and the inverse Vandermonde matrix on the nodes c_j^n turn the per-coset interpolants back into the
-    // quotient pieces (coset_combine_kernel).
+    // circuit).  twist[j][i] = c_j^i turns coefficients into values on coset j with one size-n NTT; cinv_n[j][t] =
+    // c_j^-t / n (the factors the inverse transform of the quotient's cosets stores with) and the inverse Vandermonde
+    // matrix on the nodes c_j^n turn the per-coset interpolants back into the quotient pieces (coset_combine_kernel).
     uint32_t nc = 0, nq = 0;
-    Fr *twist = nullptr, *cinv = nullptr, *vinv = nullptr;
+    Fr *twist = nullptr, *vinv = nullptr, *cinv_n = nullptr;
     // device-resident constants
     Fr *fixed_vals = nullptr, *fixed_polys = nullptr, *fixed_cos = nullptr;
     Fr *sigma_vals = nullptr, *sigma_polys = nullptr, *sigma_cos = nullptr;
@@ -290,7 +290,11 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     pk->omegas = pk->dupload(om);
     pk->x_ext = pk->dupload(xe);
     pk->twist = pk->dupload(tw);
-    pk->cinv = pk->dupload(ci);
+    {
+        const Fr n_inv = Fr::inv(Fr::from_u64(n));
+        for (Fr& v : ci) v = v * n_inv;
+        pk->cinv_n = pk->dupload(ci);
+    }
     pk->delta_pow.resize(PC);
     {
         Fr a = Fr::one();
@@ -1758,10 +1762,13 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     }
     // per-coset interpolants, then the nc x nc solve per coefficient: the quotient pieces [nc][n] (in the buffer
     // the lookup compression no longer needs)
-    ntt_launch(ctx, pr->h, pr->h, k, pk->nc, ntt_inv, st, pr->ntt_tmp);
+    // (the inverse transform's final store multiplies by c_j^-t / n instead of 1 / n: the combination is left with one
+    // product per term)
+    NttOpts ntt_inv_h = ntt_inv;
+    ntt_inv_h.out_table = pk->cinv_n;
+    ntt_launch(ctx, pr->h, pr->h, k, pk->nc, ntt_inv_h, st, pr->ntt_tmp);
     Fr* const hp = pr->aux_ext;
-    hipLaunchKernelGGL(coset_combine_kernel, dim3(ceil_div(n, 256), pk->nc), dim3(256), 0, st, pr->h, pk->cinv, pk->vinv,
-                       pk->nc, n, hp);
+    hipLaunchKernelGGL(coset_combine_kernel, dim3(ceil_div(n, 256), pk->nc), dim3(256), 0, st, pr->h, pk->vinv, pk->nc, n, hp);
     const uint32_t npieces = P.degree - 1;
     ctr += npieces;                                      // one (unused) blind per quotient piece
     SHP_REQUIRE(ctr == randomness_len(P), SHP_ERR_INTERNAL, "prove: blinding stream length");

@@ -950,17 +950,17 @@ __global__ __launch_bounds__(256, 2) void perm_quotient_kernel(PermQArgs a, Look
     st(a.h + i, h);
 }
 
-// Quotient pieces from the per-coset interpolants.  q_j = iNTT of h on coset c_j * H, so q_j[t] = c_j^t * sum_m
-// h_m[t] * (c_j^n)^m with h = sum_m X^(m n) h_m: for every coefficient index t one nc x nc Vandermonde solve
-// (matrix inverse precomputed at keygen): pieces[m][t] = sum_j vinv[m][j] * q_j[t] * c_j^-t
+// Quotient pieces from the per-coset interpolants.  The inverse transform of h on coset c_j * H gives c_j^t * sum_m
+// h_m[t] * (c_j^n)^m with h = sum_m X^(m n) h_m; its final store multiplies by c_j^-t (NttOpts::out_table), so q_j[t] here
+// is sum_m h_m[t] * (c_j^n)^m and every coefficient index t is one nc x nc Vandermonde solve (matrix inverse precomputed
+// at keygen): pieces[m][t] = sum_j vinv[m][j] * q_j[t]
 constexpr uint32_t MAX_COSETS = 16;
-// grid (n / block, nc): one thread per (piece m, coefficient t) -- 2 nc products deep instead of nc^2 + nc
-__global__ void coset_combine_kernel(const Fr* q, const Fr* cinv, const Fr* vinv, uint32_t nc, uint32_t n, Fr* pieces) {
+// grid (n / block, nc): one thread per (piece m, coefficient t) -- nc products deep instead of nc^2
+__global__ void coset_combine_kernel(const Fr* q, const Fr* vinv, uint32_t nc, uint32_t n, Fr* pieces) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     if (t >= n) return;
     Fr acc = Fr::zero();
-    for (uint32_t j = 0; j < nc; j++)
-        acc = acc + ld(vinv + m * nc + j) * (ld(q + (size_t)j * n + t) * ld(cinv + (size_t)j * n + t));
+    for (uint32_t j = 0; j < nc; j++) acc = acc + ld(vinv + m * nc + j) * ld(q + (size_t)j * n + t);
     st(pieces + (size_t)m * n + t, acc);
 }
 
