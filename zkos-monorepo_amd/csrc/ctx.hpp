@@ -73,9 +73,12 @@ struct NttOpts {
     const Fr* twist = nullptr;
     uint32_t twist_count = 0;
     // output i of transform b scaled by out_table[b * 2^log_n + i] INSTEAD of the inverse transform's 1/n (the table
-    // carries that factor): the product the final store spends on 1/n anyway does a second job
+    // carries that factor): the product the final store spends on 1/n anyway does a second job.  Every entry must also
+    // carry ntt_out_table_factor(); not together with post_pattern.
     const Fr* out_table = nullptr;
 };
+// 1, or 2^5 when the 29-bit tile is selected (SHP_NTT29=1: its factors are kept times 2^5, see ntt.hip)
+Fr ntt_out_table_factor();
 // `tmp`: caller-owned ping-pong buffer of batch * 2^log_n elements (needed when log_n > 11);
 // nullptr = the context's shared buffer (single-stream use only)
 void ntt_launch(shp_ctx* ctx, const Fr* d_in, Fr* d_out, uint32_t log_n, uint32_t batch, const NttOpts& o,

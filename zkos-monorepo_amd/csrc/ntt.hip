@@ -356,7 +356,9 @@ __global__ __launch_bounds__(THREADS) void ntt29_pass_kernel(PassParams p, Pass2
             uint32_t k1 = k1_base | col;
             go = (size_t)k1 + ((size_t)k2 << p.s1) + ((size_t)kp << (p.s1 + p.s2));
             const uint32_t m = p.post_pattern ? (uint32_t)(go % 3) : 0;
-            val = R29::mul(val, R29::split<0>(m == 0 ? q.out32[0] : m == 1 ? q.out32[1] : q.out32[2]));
+            if (p.out_table) f = gload(p.out_table + ((size_t)blockIdx.y << p.log_n) + go);   // (times 2^5, like out32)
+            else f = m == 0 ? q.out32[0] : m == 1 ? q.out32[1] : q.out32[2];
+            val = R29::mul(val, R29::split<0>(f));
         }
         Fr out = pack29(val);
         out.reduce_once();
@@ -409,6 +411,7 @@ static bool ntt29_mode() {
     return on;
 }
 static Fr table_first() { return ntt29_mode() ? Fr::from_u64(32) : Fr::one(); }
+Fr ntt_out_table_factor() { return table_first(); }
 
 // v[i] = first * base^i
 static Fr* upload_powers(const Fr& base, size_t count, const Fr& first = table_first()) {
@@ -571,6 +574,7 @@ static void ntt_launch_with(shp_ctx* ctx, const NttTables& T, uint32_t tw_shift,
                             uint32_t batch, const NttOpts& o, hipStream_t st, Fr* tmp_in) {
     const size_t N = (size_t)1 << log_n;
     const int dir = o.inverse ? 1 : 0;
+    SHP_REQUIRE(!(o.out_table && o.post_pattern), SHP_ERR_INVALID_ARG, "ntt: out_table with post_pattern");
 
     uint32_t digits[3], tile_log;
     const int P = ntt_digits(log_n, digits, tile_log);
@@ -623,7 +627,7 @@ static void ntt_launch_with(shp_ctx* ctx, const NttTables& T, uint32_t tw_shift,
         if (p.is_final) { p.dst = d_out; p.dst_stride = N; }
         else { p.dst = tmp; p.dst_stride = N; }
         uint32_t tiles = (uint32_t)(N >> (p.s + p.c));
-        if (ntt29_mode() && !o.out_table) {               // (the 29-bit tile has no per-output table)
+        if (ntt29_mode()) {
             Pass29 q;
             q.small_a = ctx->ntt_small29_a[dir];
             q.small_b = ctx->ntt_small29_b[dir];

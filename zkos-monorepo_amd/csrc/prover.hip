@@ -291,7 +291,7 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     pk->x_ext = pk->dupload(xe);
     pk->twist = pk->dupload(tw);
     {
-        const Fr n_inv = Fr::inv(Fr::from_u64(n));
+        const Fr n_inv = Fr::inv(Fr::from_u64(n)) * ntt_out_table_factor();
         for (Fr& v : ci) v = v * n_inv;
         pk->cinv_n = pk->dupload(ci);
     }
