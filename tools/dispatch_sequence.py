@@ -13,7 +13,7 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), (threads + 63) // 64, name))
     rows.sort()
     # the last proof: everything after the last SHPLONK witness kernel (the end of a proof) but one
-    first = sys.argv[2] if len(sys.argv) > 2 else "shplonk_wp_kernel"
+    first = sys.argv[2] if len(sys.argv) > 2 else "shplonk_wp_inv_kernel"
     ends = [i for i, r in enumerate(rows) if r[3].startswith(first)]
     begin = ends[-2] + 1 if len(ends) > 1 else 0
     while rows[begin][3].startswith("msm_direct"):              # the commitment of W' still belongs to the proof before

@@ -752,7 +752,7 @@ struct shp_prover {
     Fr* pw = nullptr;
     EvalJob* jobs = nullptr;                                   // fixed per prover (buffer addresses, point indices): uploaded once
     bool jobs_uploaded = false;
-    Fr *fsets = nullptr, *dinv = nullptr, *wvals = nullptr, *mdiff = nullptr;
+    Fr *fsets = nullptr, *dinv = nullptr, *wvals = nullptr;
     LincombArgs* lin = nullptr;                                // the rotation sets' polynomials: fixed per prover, uploaded once
     bool lin_uploaded = false;
     Fr* ntt_tmp = nullptr;
@@ -937,7 +937,6 @@ static void prover_create_impl(shp_pk* pk, shp_prover** out) {
     pr->fsets = pr->dalloc<Fr>((size_t)MAX_SETS * n);
     pr->dinv = pr->dalloc<Fr>((size_t)MAX_POINTS * n);
     pr->wvals = pr->dalloc<Fr>((size_t)2 * n);
-    pr->mdiff = pr->dalloc<Fr>((size_t)n);                     // 1 / (omega^r - mu)
     pr->lin = pr->dalloc<LincombArgs>(MAX_SETS);
     pr->ntt_tmp = pr->dalloc<Fr>((size_t)(NV + 1) * ne);
     pr->rank = pr->dalloc<uint32_t>((size_t)2 * L * n);
@@ -1959,10 +1958,16 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     }
     for (size_t i = sets.size(); i < (size_t)MAX_SETS; i++) wp.coef[i] = Fr::zero();
     wp.c1 = zt * d0inv;
-    wp.n_sets = sa.n_sets; wp.f = pr->fsets; wp.w = pr->wvals; wp.minv = pr->mdiff;
+    wp.n_sets = sa.n_sets; wp.f = pr->fsets; wp.w = pr->wvals;
     const Fr* d_mu = (const Fr*)staged(&mu, sizeof(Fr));
-    invert_point_diffs(d_mu, &mu, pr->mdiff, 1);
-    hipLaunchKernelGGL(shplonk_wp_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, wp, n, pr->wvals + n);
+    {
+        // 1 / (omega^r - mu) is formed inside the kernel that divides by it, from the product scans
+        pr->timers.begin(KID_BATCH_INVERT, st);
+        const InvList il = product_scans(nullptr, nullptr, 1, d_mu, &mu);
+        hipLaunchKernelGGL(sce == 1 ? shplonk_wp_inv_kernel<1> : shplonk_wp_inv_kernel<SCAN_E_POOL>, dim3(snb), dim3(sbs), 0, st, wp,
+                           pk->omegas, d_mu, pr->sc_pre, pr->sc_suf, sc_bpre, sc_bsuf, sc_inv, il, n, pr->wvals + n);
+        pr->timers.end(st);
+    }
     commit(srs->msm_gl, pr->wvals + n, 1, pts.data());
     tr.write_point(pts[0].x, pts[0].y);
     pc.mark("Wprime");

@@ -1113,15 +1113,32 @@ struct ShplonkWpArgs {                           // by value: a few hundred byte
     Fr c0, c1;                                   // sum_i coef_i R_i(mu), Z_T(mu) / diff_0
     const Fr* f;                                 // [n_sets][n] combined set polynomials (values)
     const Fr* w;                                 // W values
-    const Fr* minv;                              // 1 / (omega^r - mu)
 };
-__global__ void shplonk_wp_kernel(ShplonkWpArgs a, uint32_t n, Fr* out) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    Fr acc = Fr::zero();
-    for (uint32_t i = 0; i < a.n_sets; i++) acc = acc + a.coef[i] * ld(a.f + (size_t)i * n + r);
-    acc = acc - a.c0 - a.c1 * ld(a.w + r);
-    st(out + r, acc * ld(a.minv + r));
+// 1 / (omega^r - mu) is formed on the way from the product scans of omega^r - mu (what batch_invert_apply_kernel<E> would
+// store for product 0): no dispatch and no round trip of n values for the inverses.  Launched like scan_local_kernel<E>.
+template <int E>
+__global__ __launch_bounds__(SCAN_THREADS) void shplonk_wp_inv_kernel(ShplonkWpArgs a, const Fr* omegas, const Fr* mu, const Fr* pre,
+                                                                      const Fr* suf, const Fr* bpre, const Fr* bsuf, const Fr* inv_tot,
+                                                                      InvList il, uint32_t n, Fr* out) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.x, e0 = slot * E;
+    const Fr pt = ld(mu);
+    Fr v[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) v[j] = ld(omegas + e0 + j) - pt;
+    Fr sf[E];                              // product of every element after element j of the chunk
+    sf[E - 1] = ld(suf + slot) * ld(bsuf + k);
+#pragma unroll
+    for (int j = E - 2; j >= 0; j--) sf[j] = sf[j + 1] * v[j + 1];
+    Fr pf = ld(pre + slot) * ld(bpre + k) * (il.n ? il.v[0] : ld(inv_tot));   // (product of every element before) / total
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const uint32_t r = e0 + j;
+        Fr acc = Fr::zero();
+        for (uint32_t i = 0; i < a.n_sets; i++) acc = acc + a.coef[i] * ld(a.f + (size_t)i * n + r);
+        acc = acc - a.c0 - a.c1 * ld(a.w + r);
+        st(out + r, acc * (pf * sf[j]));
+        if (j + 1 < E) pf = pf * v[j];
+    }
 }
 
 }  // namespace shp
