@@ -24,6 +24,9 @@ enum { COL_ADVICE = 0, COL_FIXED = 1, COL_INSTANCE = 2 };
 struct Instr { uint32_t op, dst, a, b; };
 struct Query { uint32_t col; int32_t rot; };
 struct WOp { uint32_t op, dc, dr, ac, ar, bc, br, imm; };
+// a range of witness ops that is one Poseidon2 permutation written out row by row (found by the prover when it takes a
+// plan, never part of the plan's bytes): the state columns in state order, the row of the input state
+struct WPermutation { uint32_t lo, hi, r0, cols[8]; };
 struct LookupPlan {
     uint32_t m = 0, in_slots = 0, tab_slots = 0;
     std::vector<Instr> in_prog, tab_prog;
@@ -47,6 +50,7 @@ struct PlanData {
     std::vector<uint32_t> challenge_phase;                       // challenge i is squeezed after the commitments of this phase
     std::vector<uint32_t> wops_end;                              // witness ops of phase p: [wops_end[p-1], wops_end[p])
     uint8_t plan_hash[32];
+    std::vector<WPermutation> wperms;                            // sorted by lo, disjoint (see WPermutation)
     // derived
     uint32_t n = 0, usable = 0, ext_k = 0, chunk = 0, num_sets = 0;
     uint32_t adv_rows = 0;       // rows [adv_rows, usable) of every advice column are never assigned (stay zero)

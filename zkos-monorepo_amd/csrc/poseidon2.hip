@@ -26,6 +26,33 @@ static const Fr P2H_DIAG[8] = P2_DIAG_INIT;
 
 void poseidon2_permute_host(Fr s[8]) { poseidon2_permute_impl(s, P2H_RC_FULL, P2H_RC_PART, P2H_DIAG); }
 
+// (the rounds of poseidon2_permute_impl with a row stored behind every linear layer)
+void poseidon2_trace_host(Fr* grid, size_t col_stride, const uint32_t cols[8], uint32_t r0) {
+    Fr s[8];
+    for (int i = 0; i < 8; i++) s[i] = grid[(size_t)cols[i] * col_stride + r0];
+    uint32_t row = r0;
+    auto put = [&] {
+        row++;
+        for (int i = 0; i < 8; i++) grid[(size_t)cols[i] * col_stride + row] = s[i];
+    };
+    p2_external(s);
+    put();
+    for (int r = 0; r < 8; r++) {
+        if (r == 4) {
+            for (int q = 0; q < 48; q++) {
+                s[0] = p2_sbox(s[0] + P2H_RC_PART[q]);
+                Fr sum = s[0];
+                for (int i = 1; i < 8; i++) sum = sum + s[i];
+                for (int i = 0; i < 8; i++) s[i] = P2H_DIAG[i] * s[i] + sum;
+                put();
+            }
+        }
+        for (int i = 0; i < 8; i++) s[i] = p2_sbox(s[i] + P2H_RC_FULL[r][i]);
+        p2_external(s);
+        put();
+    }
+}
+
 Fr poseidon2_hash_host(const Fr* in, uint32_t arity) {
     Fr s[8];
     for (int i = 0; i < 8; i++) s[i] = Fr::zero();

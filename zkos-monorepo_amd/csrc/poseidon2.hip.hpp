@@ -62,6 +62,11 @@ SHP_HD void poseidon2_permute_impl(Fr s[8], const RCF& rc_full, const RCP& rc_pa
 }
 
 void poseidon2_permute_host(Fr s[8]);
+// The permutation's states row by row, as the circuits' Poseidon2 chip lays them out: cell (cols[i], r0) of the column-major
+// grid (col_stride cells a column) holds the input state; row r0 + 1 receives the state after the first linear layer,
+// then one row per round (4 full, 48 partial, 4 full): rows r0 + 1 .. r0 + 56 are written.
+constexpr uint32_t P2_TRACE_ROWS = 56;
+void poseidon2_trace_host(Fr* grid, size_t col_stride, const uint32_t cols[8], uint32_t r0);
 Fr poseidon2_hash_host(const Fr* in, uint32_t arity);
 
 }  // namespace shp

@@ -235,6 +235,7 @@ static void launch_prog(hipStream_t st, const ProgArgs& a, uint32_t size, bool t
 // transcript_repr_le32 (optional): the first word of the transcript, 32-byte little-endian canonical -- halo2's
 // vk.transcript_repr() (absorbed at /root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:247-248, emitted at
 // src/lib/codegen.rs:162) for callers that hold the halo2 VerifyingKey; nullptr = the library's own digest.
+static void find_witness_permutations(PlanData& P);
 static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, size_t len, shp_pk** out,
                         const std::vector<G1Affine>* stored_comm = nullptr, const uint8_t* transcript_repr_le32 = nullptr) {
     SHP_REQUIRE(ctx && srs && plan_bytes && out, SHP_ERR_INVALID_ARG, "keygen: null argument");
@@ -245,6 +246,7 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     pk->plan_bytes.assign(plan_bytes, plan_bytes + len);
     PlanData& P = pk->plan;
     P.parse(plan_bytes, len);
+    find_witness_permutations(P);
     SHP_REQUIRE(P.k == srs->k, SHP_ERR_INVALID_ARG, "keygen: plan k differs from the SRS k");
     SHP_REQUIRE(P.n >= 64 && P.k <= 16 && P.perm_cols.size() <= MAX_PERM_COLS, SHP_ERR_INVALID_ARG,
                 "keygen: unsupported plan shape");
@@ -458,7 +460,18 @@ static void run_witness_range(const PlanData& P, const std::vector<Fr>& inputs, 
                               uint32_t lo, uint32_t hi, const Fr* chal = nullptr /* the challenges squeezed so far */) {
     const uint32_t A = P.num_advice, n = P.n;
     auto cell = [&](uint32_t c, uint32_t r) -> Fr& { return c == A ? scratch[r] : grid[(size_t)c * n + r]; };
+    // ranges that are whole Poseidon2 permutations run natively (find_witness_permutations): the first one at or after lo
+    size_t wp = std::lower_bound(P.wperms.begin(), P.wperms.end(), lo, [](const WPermutation& a, uint32_t v) { return a.lo < v; }) -
+                P.wperms.begin();
     for (uint32_t i = lo; i < hi; i++) {
+        if (wp < P.wperms.size() && P.wperms[wp].lo == i) {
+            const WPermutation& f = P.wperms[wp++];
+            if (f.hi <= hi) {
+                poseidon2_trace_host(grid, n, f.cols, f.r0);
+                i = f.hi - 1;
+                continue;
+            }
+        }
         const WOp& w = P.wops[i];
         Fr v;
         switch (w.op) {
@@ -496,6 +509,116 @@ static void run_witness_range(const PlanData& P, const std::vector<Fr>& inputs, 
     }
 }
 
+// The circuits' Poseidon2 chip writes a permutation out as ~1770 cell operations (an S-box is one, a linear layer two
+// dozen additions), and the interpreter above spends 31 us on them where the permutation itself takes 12.  Ranges of the
+// witness program that ARE such a permutation are found here, once per key, and run natively from then on
+// (poseidon2_trace_host).  Nothing is assumed about how a plan was produced:
+//   * shape: a range that starts at an op reading the grid, reads grid cells of at most eight columns in rows
+//     r0 .. r0 + 55 only, reads no scratch cell it has not written, takes no witness input or challenge, and writes every
+//     cell of those columns' rows r0 + 1 .. r0 + 56 exactly once and no other grid cell;
+//   * what it leaves in scratch is not read afterwards (a later op writes a scratch cell before it reads it);
+//   * meaning: on two random input states the interpreted range and the native permutation (state order = ascending
+//     column index) fill the 456 cells with the same values -- the cells are polynomials of degree < 7^60 < 2^169 in the
+//     input state, so two different fillings agree on a random state with probability < 2^-84.
+// A plan without such ranges, or with another hash in the same shape, is interpreted as before.  SHP_WITNESS_NATIVE=0
+// turns the search off.
+static void find_witness_permutations(PlanData& P) {
+    P.wperms.clear();
+    static const bool off = getenv("SHP_WITNESS_NATIVE") && atoi(getenv("SHP_WITNESS_NATIVE")) == 0;
+    const uint32_t A = P.num_advice, n = P.n, nops = (uint32_t)P.wops.size(), ns = std::max<uint32_t>(P.n_wscratch, 1);
+    if (off || nops < 64 * P2_TRACE_ROWS / 8 || A < 8) return;
+    auto n_reads = [](const WOp& w) {
+        switch (w.op) {
+            case W_INPUT: case W_CONST: case W_CHAL: return 0;
+            case W_ADD: case W_SUB: case W_MUL: return 2;
+            default: return 1;
+        }
+    };
+    std::vector<Fr> grid, ref, scratch(ns);
+    std::vector<uint8_t> written;                         // per candidate: scratch cells written, then grid cells written
+    const std::vector<Fr> no_inputs;
+    uint32_t i = 0;
+    while (i < nops) {
+        const WOp& first = P.wops[i];
+        // a start: reads the grid, writes scratch
+        if (!(n_reads(first) >= 1 && first.ac != A && first.dc == A) || first.ar + P2_TRACE_ROWS >= P.usable) { i++; continue; }
+        const uint32_t r0 = first.ar;
+        uint32_t cols[8], n_cols = 0, cells = 0, j = i;
+        bool ok = true;
+        written.assign(ns + 8 * (size_t)P2_TRACE_ROWS, 0);
+        auto col_index = [&](uint32_t c) -> int {
+            for (uint32_t q = 0; q < n_cols; q++)
+                if (cols[q] == c) return (int)q;
+            if (n_cols == 8) return -1;
+            cols[n_cols] = c;
+            return (int)n_cols++;
+        };
+        for (; j < nops && ok && cells < 8 * P2_TRACE_ROWS; j++) {
+            const WOp& w = P.wops[j];
+            if (w.op == W_INPUT || w.op == W_CHAL || w.op > W_SHR) { ok = false; break; }
+            const uint32_t rc[2][2] = {{w.ac, w.ar}, {w.bc, w.br}};
+            for (int q = 0; q < n_reads(w) && ok; q++) {
+                if (rc[q][0] == A) ok = rc[q][1] < ns && written[rc[q][1]];
+                else ok = rc[q][1] >= r0 && rc[q][1] < r0 + P2_TRACE_ROWS && col_index(rc[q][0]) >= 0;
+            }
+            if (!ok) break;
+            if (w.dc == A) {
+                ok = w.dr < ns;
+                if (ok) written[w.dr] = 1;
+            } else {
+                const int q = col_index(w.dc);
+                ok = q >= 0 && w.dr > r0 && w.dr <= r0 + P2_TRACE_ROWS;
+                if (ok) {
+                    uint8_t& seen = written[ns + (size_t)q * P2_TRACE_ROWS + (w.dr - r0 - 1)];
+                    ok = !seen;
+                    seen = 1;
+                    cells++;
+                }
+            }
+        }
+        if (!ok || cells != 8 * P2_TRACE_ROWS || n_cols != 8) { i++; continue; }
+        const uint32_t hi = j;
+        // what the range leaves in scratch must be dead
+        {
+            std::vector<uint8_t> dirty(written.begin(), written.begin() + ns);
+            for (uint32_t t = hi; t < nops && ok; t++) {
+                const WOp& w = P.wops[t];
+                const uint32_t rc[2][2] = {{w.ac, w.ar}, {w.bc, w.br}};
+                for (int q = 0; q < n_reads(w); q++)
+                    if (rc[q][0] == A && rc[q][1] < ns && dirty[rc[q][1]]) ok = false;
+                if (w.dc == A && w.dr < ns) dirty[w.dr] = 0;
+            }
+        }
+        if (!ok) { i++; continue; }
+        std::sort(cols, cols + 8);
+        // the same values from both, on two random states
+        grid.assign((size_t)A * n, Fr::zero());
+        ref.assign((size_t)A * n, Fr::zero());
+        uint32_t key[8] = {0x50325452u, i, r0, 0, 0, 0, 0, 0};
+        for (uint32_t trial = 0; trial < 2 && ok; trial++) {
+            for (uint32_t q = 0; q < 8; q++) {
+                const Fr v = fr_draw(key, (uint64_t)trial * 8 + q);
+                grid[(size_t)cols[q] * n + r0] = v;
+                ref[(size_t)cols[q] * n + r0] = v;
+            }
+            WPermutation probe{i, hi, r0, {cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], cols[6], cols[7]}};
+            std::vector<WPermutation> none;
+            none.swap(P.wperms);                          // interpret: no native ranges while probing
+            run_witness_range(P, no_inputs, ref.data(), scratch.data(), i, hi);
+            none.swap(P.wperms);
+            poseidon2_trace_host(grid.data(), n, probe.cols, r0);
+            for (uint32_t q = 0; q < 8 && ok; q++)
+                ok = memcmp(&grid[(size_t)cols[q] * n + r0], &ref[(size_t)cols[q] * n + r0], (P2_TRACE_ROWS + 1) * sizeof(Fr)) == 0;
+        }
+        if (!ok) { i++; continue; }
+        P.wperms.push_back(WPermutation{i, hi, r0, {cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], cols[6], cols[7]}});
+        i = hi;
+    }
+    if (getenv("SHP_PHASE_TRACE"))
+        fprintf(stderr, "[witness] %zu Poseidon2 permutations of the program run natively (%u of %u ops)\n", P.wperms.size(),
+                (uint32_t)(P.wperms.size() ? P.wperms.size() * (P.wperms[0].hi - P.wperms[0].lo) : 0), nops);
+}
+
 // ---- witness schedule: the program cut into tasks that may run on several host threads ------
 // The witness program is a straight-line list of cell operations; at k = 13 it is ~40 k operations
 // (19 Poseidon2 permutations) = 0.44 ms of a 3.5 ms proof on one core, and most of it is independent
@@ -511,6 +634,7 @@ struct WitnessSchedule {
     struct Range { uint32_t lo, hi; };
     uint32_t n_threads = 1;
     bool serial_tail = false;                               // the last level runs on the calling thread in program order
+    bool main_spared = false;                               // the calling thread has that tail only and joins no level's barrier
     std::vector<std::vector<std::vector<Range>>> plan;      // [level][thread] -> ranges
 
     // spare_main: the calling thread gets no tasks of its own (it has kernels to launch while the helpers work) -- only
@@ -518,6 +642,7 @@ struct WitnessSchedule {
     void build(const PlanData& P, uint32_t threads, bool spare_main = false) {
         n_threads = threads;
         serial_tail = false;
+        main_spared = false;
         plan.clear();
         const uint32_t A = P.num_advice, n = P.n, nops = (uint32_t)P.wops.size();
         if (threads <= 1 || nops == 0) return;
@@ -625,6 +750,7 @@ struct WitnessSchedule {
             }
         }
         // 3. per level: longest tasks first onto the least loaded thread
+        main_spared = spare_main && threads > 1;
         plan.assign(n_levels, std::vector<std::vector<Range>>(threads));
         for (uint32_t lv = 0; lv < n_levels; lv++) {
             std::vector<const Task*> at;
@@ -684,13 +810,38 @@ struct WitnessWorkers {
         cv.notify_all();
         for (auto& t : th) t.join();
     }
+    // a level's barrier: a short busy wait (the levels of a proof are microseconds apart), then yielding
+    void await(uint64_t target) {
+        for (uint32_t spins = 0; arrivals.load(std::memory_order_acquire) < target; spins++) {
+#if defined(__x86_64__)
+            if (spins < 4096) { __builtin_ia32_pause(); continue; }
+#endif
+            std::this_thread::yield();
+        }
+    }
     void levels(uint32_t tid) {
         const uint32_t nl = (uint32_t)sched->plan.size();
+        if (sched->main_spared) {
+            // The calling thread has kernels to launch meanwhile: it joins no barrier (the helpers would wait for it at
+            // the first one), waits for their last level and runs the serial tail, if any, itself.
+            const uint32_t par = sched->serial_tail ? nl - 1 : nl, parts = T - 1;
+            if (tid == 0) {
+                await(base + (uint64_t)par * parts);
+                if (sched->serial_tail)
+                    for (const auto& r : sched->plan[nl - 1][0]) run_witness_range(*P, *inputs, grid, scratch[0].data(), r.lo, r.hi);
+                return;
+            }
+            for (uint32_t lv = 0; lv < par; lv++) {
+                for (const auto& r : sched->plan[lv][tid]) run_witness_range(*P, *inputs, grid, scratch[tid].data(), r.lo, r.hi);
+                arrivals.fetch_add(1, std::memory_order_acq_rel);
+                await(base + (uint64_t)(lv + 1) * parts);
+            }
+            return;
+        }
         for (uint32_t lv = 0; lv < nl; lv++) {
             for (const auto& r : sched->plan[lv][tid]) run_witness_range(*P, *inputs, grid, scratch[tid].data(), r.lo, r.hi);
             arrivals.fetch_add(1, std::memory_order_acq_rel);
-            const uint64_t target = base + (uint64_t)(lv + 1) * T;
-            while (arrivals.load(std::memory_order_acquire) < target) std::this_thread::yield();
+            await(base + (uint64_t)(lv + 1) * T);
         }
     }
     void worker(uint32_t tid) {
