@@ -256,6 +256,14 @@ int32_t shp_pk_info(const shp_pk* pk, uint32_t* k, uint32_t* n_witness_inputs, u
  *   *compiled = 0  everything is interpreted (any other plan, or SHP_GATE_AOT=0 in the environment at keygen).
  * Proof bytes do not depend on it. */
 int32_t shp_pk_gate_compiled(const shp_pk* pk, int32_t* compiled);
+/* How much of the key's witness program (what the circuit's `synthesize` does in the reference,
+ * /root/reference/crates/shielder_bindings/src/circuits/mod.rs:103-111; the circuits themselves are the shielder-circuits
+ * dependency, /root/reference/Cargo.toml:63) runs as native code instead of cell by cell: the library finds the ranges of a
+ * plan's program that are whole Poseidon2 permutations written out row by row (the circuits' Poseidon2 chip; the
+ * permutation of /root/reference/poseidon2-solidity/generate_t8.py:474-588) and runs the permutation itself for them.
+ * *ranges = such ranges, *ops = the operations they cover, *total_ops = the program's.  No counterpart in the reference
+ * (a diagnostic); cell values, hence proof bytes, do not depend on it.  SHP_WITNESS_NATIVE=0 at keygen: none. */
+int32_t shp_pk_witness_native(const shp_pk* pk, uint32_t* ranges, uint32_t* ops, uint32_t* total_ops);
 /* verifying-key material: transcript digest, fixed and permutation commitments (64 B affine each) */
 int32_t shp_pk_vk_digest(const shp_pk* pk, uint8_t out[32]);
 int32_t shp_pk_commitments(const shp_pk* pk, void* h_fixed, size_t n_fixed, void* h_sigma, size_t n_sigma);

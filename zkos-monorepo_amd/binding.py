@@ -500,6 +500,13 @@ class ProvingKey:
         _check(lib().shp_pk_gate_compiled(self.h, C.byref(v)))
         return v.value
 
+    def witness_native(self):
+        """(ranges, ops, total_ops): the ranges of the witness program that run as native Poseidon2 permutations, the
+        operations they cover, the program's length"""
+        r, o, t = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _check(lib().shp_pk_witness_native(self.h, C.byref(r), C.byref(o), C.byref(t)))
+        return r.value, o.value, t.value
+
     def vk_digest(self) -> bytes:
         out = C.create_string_buffer(32)
         _check(lib().shp_pk_vk_digest(self.h, out))

@@ -2358,6 +2358,16 @@ int32_t shp_pk_gate_compiled(const shp_pk* pk, int32_t* compiled) {
     });
 }
 
+int32_t shp_pk_witness_native(const shp_pk* pk, uint32_t* ranges, uint32_t* ops, uint32_t* total_ops) {
+    return guarded([&] {
+        SHP_REQUIRE(pk && ranges && ops && total_ops, SHP_ERR_INVALID_ARG, "pk_witness_native: null argument");
+        *ranges = (uint32_t)pk->plan.wperms.size();
+        *ops = 0;
+        for (const WPermutation& w : pk->plan.wperms) *ops += w.hi - w.lo;
+        *total_ops = (uint32_t)pk->plan.wops.size();
+    });
+}
+
 int32_t shp_pk_vk_digest(const shp_pk* pk, uint8_t out[32]) {
     return guarded([&] {
         SHP_REQUIRE(pk && out, SHP_ERR_INVALID_ARG, "pk_vk_digest: null argument");
