@@ -1409,11 +1409,22 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     // element, 17 windows instead of the 19 a second table of affordable size would have, and no second table (82 GB).
     Fr* const rand_lag = pr->lag2 + n;                   // also what the evaluation-form opening reads later
     auto rand_values = [&] { ntt_launch(ctx, pr->rand_poly, rand_lag, k, 1, ntt_fwd, st, pr->ntt_tmp); };
-    if (split_commits) {
+    bool rand_launched = false;
+    auto launch_rand = [&] {
+        if (!split_commits || rand_launched) return;
         ingest(A + 1, 1, 0, 0);
         rand_values();
         commit_launch(pr->msm_ws_rand, srs->msm_gl, rand_lag, 1, &rand_comm);
+        rand_launched = true;
+    };
+    // (a proof whose lookups go ahead of the witness queues their kernels first: they are what the advice commitment will
+    // wait for, this commitment only has to be there by the grand products')
+    bool lookups_may_go_ahead = !assigned && !phased && !pr->early_ranges.empty() && P.adv_rows >= pr->dev_rows;
+    {
+        static const bool off = getenv("SHP_EARLY_LOOKUPS") && atoi(getenv("SHP_EARLY_LOOKUPS")) == 0;
+        if (off) lookups_may_go_ahead = false;
     }
+    if (!lookups_may_go_ahead) launch_rand();
     // ---- P0/P1: witness, blinding rows, instance column
     std::vector<Fr> instances;
     Fr* const grid = pr->h_grid;                        // pinned: [A][n] advice, then the instance column
@@ -1580,6 +1591,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
                 SHP_HIP(hipEventRecord(pr->ev2, pr->st2));
                 lookups_ahead = true;
             }
+            launch_rand();
             // no per-proof clearing: the program writes the same cells every time (fixed plan), the blinding rows are
             // redrawn below, everything else has been zero since prover_create
             if (started.w) started.join();
