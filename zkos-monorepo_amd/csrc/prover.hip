@@ -890,6 +890,7 @@ struct shp_prover {
     MsmWorkspace msm_ws;
     PowTable pow_table = {};               // the opening points squared out (powers_kernel)
     MsmWorkspace msm_ws_rand;              // a lone proof commits to its random polynomial while the host still runs the witness program
+    MsmWorkspace msm_ws_perm;              // ... and to its lookups' permuted columns, when those go ahead of the witness
     KernelTimers timers;
     uint64_t proofs_done = 0;
     // device workspace
@@ -945,12 +946,14 @@ struct shp_prover {
     // stream while the first one commits and builds the grand products (a lone proof): ev_cols = those columns are on the
     // device, ev_tr = their cosets are.  ntt_tmp2 is that stream's transform scratch.
     hipEvent_t ev_cols = nullptr, ev_tr = nullptr;
+    hipEvent_t ev_in = nullptr;                    // the second stream has read the advice columns it took ahead
     Fr* ntt_tmp2 = nullptr;
     void second_stream() {                         // created on first use: pool lanes never need it
         if (!st2) SHP_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));   // default priority
         if (!ev2) SHP_HIP(hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
         if (!ev_cols) SHP_HIP(hipEventCreateWithFlags(&ev_cols, hipEventDisableTiming));
         if (!ev_tr) SHP_HIP(hipEventCreateWithFlags(&ev_tr, hipEventDisableTiming));
+        if (!ev_in) SHP_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
     }
     std::vector<WitnessSchedule::Range> early_ranges;
     std::vector<uint32_t> early_cols;
@@ -976,12 +979,14 @@ struct shp_prover {
         if (ev2) (void)hipEventDestroy(ev2);
         if (ev_cols) (void)hipEventDestroy(ev_cols);
         if (ev_tr) (void)hipEventDestroy(ev_tr);
+        if (ev_in) (void)hipEventDestroy(ev_in);
         if (st2) (void)hipStreamDestroy(st2);
         stage.release();
         h_rand.release();
         for (void* p : owned) (void)hipFree(p);
         msm_ws.release();
         msm_ws_rand.release();
+        msm_ws_perm.release();
         if (h_grid) (void)hipHostFree(h_grid);
         if (own_stream && st) (void)hipStreamDestroy(st);
     }
@@ -1354,6 +1359,10 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         sync_stream(st);
         pr->msm_ws.pend_total = pr->msm_ws_rand.pend_total = 0;
     }
+    if (pr->msm_ws_perm.pend_total) {
+        sync_stream(pr->st2);
+        pr->msm_ws_perm.pend_total = 0;
+    }
     // Commitments in two halves (msm_launch_jobs / msm_finish_jobs) for a lone proof's lane: work that does not depend on the
     // next challenge is queued BEHIND the commitment kernel and runs while the host waits for the points (their stamps in
     // pinned memory, not the stream), normalises and hashes them.  Pool lanes, lanes behind a combiner and profiled lanes
@@ -1452,7 +1461,8 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     std::vector<Fr> hb;                                 // host staging of blinding values
     // P3's device work up to the permuted columns V(I_PIN ...): compress the lookups' expressions with theta, sort, permute,
     // blind.  Returns the per-lookup error words (pinned; valid once the stream has passed the flags kernel).
-    auto lookup_columns = [&](const Fr& theta, hipStream_t ls) -> uint32_t* {
+    // after_reads: recorded on ls once the advice columns have been read (behind the compression)
+    auto lookup_columns = [&](const Fr& theta, hipStream_t ls, hipEvent_t after_reads = nullptr) -> uint32_t* {
         for (uint32_t l = 0; l < L; l++) {
             const LookupPlan& lk = P.lookups[l];
             lagrange_domain(pa);
@@ -1469,6 +1479,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             launch_prog(ls, pa, n, pr->throughput, &pt);
             pa.out_raw = nullptr;
         }
+        if (after_reads) SHP_HIP(hipEventRecord(after_reads, ls));
         pr->timers.begin(KID_RANK_SORT, ls);
         SHP_REQUIRE(2 * L <= pr->sc_cnt, SHP_ERR_INVALID_ARG, "prove: too many lookups for the sort scratch");
         hipLaunchKernelGGL(sort_tiles_kernel, dim3(ceil_div(u, SORT_TILE), 2 * L), dim3(512), 0, ls, pr->sort_raw, pr->sc_pre,
@@ -1585,10 +1596,17 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
                     k0 = k1;
                 }
                 ctr = lookup_ctr0;                            // the lookups' blinding values sit behind the advice columns'
-                early_err = lookup_columns(Fr::zero(), pr->st2);
+                early_err = lookup_columns(Fr::zero(), pr->st2, pr->ev_in);
                 SHP_REQUIRE(ctr == lookup_ctr1, SHP_ERR_INTERNAL, "prove: blinding stream position of the lookups");
                 ctr = 0;
                 SHP_HIP(hipEventRecord(pr->ev2, pr->st2));
+                // their commitment follows them on that stream, in a launch of its own: it waits neither for the witness
+                // nor for the advice commitment, and the transcript takes its points behind the advice columns' all the same
+                {
+                    MsmJob pj{srs->msm_gl, V(I_PIN), n, 2 * L, MsmRows{n, 0, 0}, pts.data() + A};
+                    pr->msm_ws_perm.poll_results = true;
+                    msm_launch_jobs(&pj, 1, pr->msm_ws_perm, pr->st2);
+                }
                 lookups_ahead = true;
             }
             launch_rand();
@@ -1624,15 +1642,17 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         if (split_commits) {
             // witness rows and instances in one dispatch; the random polynomial is on its way already
             if (lookups_ahead) {
-                // behind the second stream's work (long done by now): the columns that went ahead are simply uploaded again
-                // with the others, one dispatch for all
-                SHP_HIP(hipStreamWaitEvent(st, pr->ev2, 0));
+                // the columns that went ahead are simply uploaded again with the others, one dispatch for all, once the second
+                // stream has read them (long ago); their permuted columns have a commitment launch of their own there
+                SHP_HIP(hipStreamWaitEvent(st, pr->ev_in, 0));
                 ingest(0, A + 1, rows_now, (uint32_t)instances.size());
             } else {
                 ingest(0, A + 1, rows_now, (uint32_t)instances.size());
-                if (early_lookups) early_err = lookup_columns(Fr::zero(), st);
+                if (early_lookups) {
+                    early_err = lookup_columns(Fr::zero(), st);
+                    jobs[n_jobs++] = MsmJob{srs->msm_gl, V(I_PIN), n, 2 * L, MsmRows{n, 0, 0}, pts.data() + A};
+                }
             }
-            if (early_lookups) jobs[n_jobs++] = MsmJob{srs->msm_gl, V(I_PIN), n, 2 * L, MsmRows{n, 0, 0}, pts.data() + A};
             pr->msm_ws.poll_results = true;
             // every column in front of the grand products is final now: its coefficient form and cosets (P9) are computed on
             // the second stream, next to this commitment and the grand products, instead of behind them
@@ -1777,6 +1797,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             SHP_REQUIRE(herr[l] == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
         for (uint32_t i = 0; i < 2 * L; i++) tr.write_point(pts[i].x, pts[i].y);
     } else if (L) {
+        if (lookups_ahead) msm_finish_jobs(pr->msm_ws_perm, pr->st2);
         for (uint32_t l = 0; l < L; l++)
             SHP_REQUIRE(early_err[l] == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
         for (uint32_t i = 0; i < 2 * L; i++) tr.write_point(pts[A + i].x, pts[A + i].y);
