@@ -266,6 +266,7 @@ int32_t shp_ctx_destroy(shp_ctx* ctx) {
                 (void)hipFree(kv.second.hi[d]);
                 for (int q = 0; q < 2; q++)
                     if (kv.second.pass[d][q]) (void)hipFree(kv.second.pass[d][q]);
+                if (kv.second.dit[d]) (void)hipFree(kv.second.dit[d]);
             }
         ctx->ntt_tmp.release();
         ntt_static_teardown(ctx);

@@ -21,6 +21,9 @@ struct NttTables {
     Fr* lo[2] = {nullptr, nullptr};      // [0] forward, [1] inverse
     Fr* hi[2] = {nullptr, nullptr};
     Fr* pass[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    // dit[d][2^j - 1 + k] = w_(2^(j+1))^k, k < 2^j: every butterfly twiddle of the decimation-in-time transform, stage by
+    // stage (2^log_n - 1 entries; see ntt_dit_pass_kernel)
+    Fr* dit[2] = {nullptr, nullptr};
     Fr n_inv;
 };
 
@@ -76,7 +79,17 @@ struct NttOpts {
     // carries that factor): the product the final store spends on 1/n anyway does a second job.  Every entry must also
     // carry ntt_out_table_factor(); not together with post_pattern.
     const Fr* out_table = nullptr;
+    // The same coset evaluation with the twist folded into the butterflies' twiddles (ntt_dit_pass_kernel): per coset a
+    // table built by ntt_build_coset_table, [coset_count][2^log_n]; output = coset_g * (values on the coset) when
+    // coset_scaled.  A caller sets it NEXT TO `twist`: the launcher takes whichever path is enabled.
+    const Fr* coset_tw = nullptr;
+    Fr coset_g;
+    bool coset_scaled = false;
 };
+// table[2^j - 1 + k] = (c w_N^k)^(2^(log_n - 1 - j)), k < 2^j, j < log_n, with entry 0 times g: the twiddles of a
+// decimation-in-time transform onto the coset c H (c = 1: onto H itself); `out` holds 2^log_n elements
+bool ntt_dit_enabled();                // false with SHP_NTT_DIT=0 (or SHP_NTT29=1): every transform takes ntt_pass_kernel
+void ntt_build_coset_table(shp_ctx* ctx, uint32_t log_n, const Fr& c, const Fr& g, bool inverse, Fr* out, hipStream_t st);
 // 1, or 2^5 when the 29-bit tile is selected (SHP_NTT29=1: its factors are kept times 2^5, see ntt.hip)
 Fr ntt_out_table_factor();
 // `tmp`: caller-owned ping-pong buffer of batch * 2^log_n elements (needed when log_n > 11);

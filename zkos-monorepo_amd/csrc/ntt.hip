@@ -49,6 +49,13 @@ struct PassParams {
     const Fr* twist;          // first pass only (null: none)
     uint32_t src_div;         // first pass: transforms per input polynomial (>= 1)
     const Fr* out_table;      // final pass only (null: none): per-output factors [transform][2^log_n], in place of `scale`
+    // ntt_dit_pass_kernel only
+    uint32_t j0;              // stages done by the passes before this one
+    const Fr* dit_tw;         // twiddles by stage: [2^j - 1 + k]; one table per coset when dit_cosets > 1
+    uint32_t dit_cosets;      // transforms per input polynomial (1: the plain transform, whose k = 0 twiddles are one)
+    int dit_plain;            // the table's k = 0 entries are one: those butterflies skip the product
+    int dit_scaled;           // the transform's very first stage also multiplies its first operand by dit_g (2: dit_g = 32, by shifts)
+    Fr dit_g;
 };
 
 __device__ __forceinline__ Fr lds_load(const uint4* lo, const uint4* hi, uint32_t i) {
@@ -184,6 +191,155 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
         }
         gstore(dst + go, val);
     }
+}
+
+// ------------------------------------------------------------------ decimation in time, every factor in the butterflies
+// The transform as the textbook in-place decimation in time, read in the index space of the INPUT: stage j (0 <= j <
+// log_n) pairs the elements whose indices differ in bit log_n - 1 - j, (a, b) -> (a + t b, a - t b), and the twiddle t =
+// w_(2^(j+1))^k depends on the j bits ABOVE that bit alone (k = those bits reversed); after the last stage position i holds
+// output bitrev(i).  A pass takes the next s bits from the top: its tile is every element that agrees in the bits above
+// (already done) and below (still to do), 2^c neighbours wide as in ntt_pass_kernel, so the passes need no transposition
+// and -- the point -- NO product between them: the factor w_N^(k_p lo) that the decomposition N = L1 L2 pays per element
+// at the pass boundary is what makes the later stages' twiddles differ from tile to tile here (they come from a table of
+// all 2^log_n - 1 of them, a tile of the final pass reads the 2^s - 1 per column it needs, neighbouring columns
+// neighbouring entries).  A coset c H costs nothing either: f(c w^k) = f_e(c^2 w^2k) + c w^k f_o(c^2 w^2k), so stage j's
+// twiddles are the plain ones times c^(2^(log_n-1-j)) -- a table per coset (ntt_build_coset_table) instead of a product
+// per input coefficient.  Per element of a 2^13 coset transform: 6.5 products (7 with a scale factor on the outputs,
+// which takes a second product in the first stage) against 3.5 + 3 in the butterflies + 1 twist + 1 between the passes.
+// 32 x mod p without a product: x < p < 2^254 shifted up five bits, minus q p for q = (its top 32 bits) / (the modulus's top
+// 27 bits + 1) -- never above floor(32 x / p) and at most one below it -- leaves less than 2 p
+__device__ __forceinline__ Fr fr_times32(const Fr& x) {
+    uint32_t t[9];
+    t[0] = x.l[0] << 5;
+#pragma unroll
+    for (int i = 1; i < 8; i++) t[i] = (x.l[i] << 5) | (x.l[i - 1] >> 27);
+    t[8] = x.l[7] >> 27;
+    constexpr uint32_t P27 = (FrParams::p(7) >> 3) + 1;
+    const uint32_t q = ((t[8] << 29) | (t[7] >> 3)) / P27;
+    Fr r;
+    uint64_t carry = 0, borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint64_t m = (uint64_t)q * FrParams::p(i) + carry;
+        carry = m >> 32;
+        const uint64_t d = (uint64_t)t[i] - (uint32_t)m - borrow;
+        r.l[i] = (uint32_t)d;
+        borrow = (d >> 32) & 1;
+    }
+    r.reduce_once();
+    return r;
+}
+
+template <int THREADS, int TILE_LOG>
+__global__ __launch_bounds__(THREADS) void ntt_dit_pass_kernel(PassParams p) {
+    __shared__ uint4 sh_lo[1 << TILE_LOG];
+    __shared__ uint4 sh_hi[1 << TILE_LOG];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t poly = p.is_first ? blockIdx.y / p.dit_cosets : blockIdx.y;
+    const Fr* src = p.src + (size_t)poly * p.src_stride;
+    Fr* dst = p.dst + (size_t)blockIdx.y * p.dst_stride;
+    const Fr* tw = p.dit_tw + ((size_t)(blockIdx.y % p.dit_cosets) << p.log_n);
+    const uint32_t s = p.s, c = p.c, j0 = p.j0;
+    const uint32_t L = 1u << s, V = 1u << c, E = L << c;
+    const uint32_t lo_bits = p.lo_bits;                    // index bits below this pass's (0 in the final pass)
+
+    // ---- tile coordinates.  Not final: one value `a` of the bits above, V adjacent values of the bits below.  Final: V
+    // values of `a` that differ in their TOP c bits -- their outputs are neighbours in the bit-reversed (natural) order.
+    uint32_t a_fix = 0, lo_base = 0;
+    if (!p.is_final) {
+        const uint32_t lo_tiles_log = lo_bits - c;
+        a_fix = tile >> lo_tiles_log;
+        lo_base = (tile & ((1u << lo_tiles_log) - 1)) << c;
+    } else {
+        a_fix = tile;                                       // the low j0 - c bits of a
+    }
+    auto brev = [](uint32_t x, uint32_t bits) -> uint32_t { return bits ? __brev(x) >> (32 - bits) : 0; };
+
+    // ---- this thread's butterflies: one per stage (a tile has at most twice as many elements as the workgroup threads), in
+    // column v_t; the twiddle of stage jj sits at tw_index(jj) and is requested one stage ahead -- the first one before
+    // the tile is loaded -- so that a table entry that comes from the L2 or beyond arrives behind a barrier, not in front
+    // of the product
+    const bool active = tid < (E >> 1);
+    const uint32_t v_t = tid & (V - 1), jbb = tid >> c;
+    const uint32_t a_t = p.is_final ? ((v_t << (j0 - c)) | a_fix) : a_fix;
+    const uint32_t ra_t = brev(a_t, j0);
+    auto tw_k = [&](uint32_t jj) -> uint32_t { return (brev(jbb >> (s - 1 - jj), jj) << j0) | ra_t; };
+    Fr w_next = Fr::zero();
+    if (active && s) w_next = gload(tw + (((size_t)1 << j0) - 1 + tw_k(0)));
+
+    // ---- load HBM -> LDS, [element of the pass][column]
+    for (uint32_t e = tid; e < E; e += THREADS) {
+        size_t gi;
+        uint32_t li;
+        if (!p.is_final) {
+            const uint32_t v = e & (V - 1), jb = e >> c;
+            gi = ((size_t)a_fix << (s + lo_bits)) | ((size_t)jb << lo_bits) | (lo_base | v);
+            li = e;
+        } else {
+            const uint32_t jb = e & (L - 1), v = e >> s;
+            const uint32_t a = (v << (j0 - c)) | a_fix;
+            gi = ((size_t)a << s) | jb;
+            li = jb * V + v;
+        }
+        lds_store(sh_lo, sh_hi, li, gload(src + gi));
+    }
+    __syncthreads();
+
+    // ---- s stages, one butterfly per thread and stage
+    for (uint32_t jj = 0; jj < s; jj++) {
+        const uint32_t t = s - 1 - jj, half = 1u << t, j = j0 + jj;
+        const Fr w = w_next;
+        const uint32_t k = tw_k(jj);
+        if (active && jj + 1 < s) w_next = gload(tw + (((size_t)1 << (j + 1)) - 1 + tw_k(jj + 1)));
+        if (active) {
+            const uint32_t grp = jbb >> t, pos = jbb & (half - 1);
+            const uint32_t jA = (grp << (t + 1)) | pos;
+            const uint32_t i0 = jA * V + v_t, i1 = (jA + half) * V + v_t;
+            Fr x = lds_load(sh_lo, sh_hi, i0);
+            Fr y = lds_load(sh_lo, sh_hi, i1);
+            if (k || !p.dit_plain) y = y * w;
+            if (p.dit_scaled && j == 0) x = p.dit_scaled == 2 ? fr_times32(x) : x * p.dit_g;
+            lds_store(sh_lo, sh_hi, i0, x + y);
+            lds_store(sh_lo, sh_hi, i1, x - y);
+        }
+        __syncthreads();
+    }
+
+    // ---- store LDS -> HBM: in place between passes; bit-reversed = natural order, V adjacent outputs a run, at the end
+    for (uint32_t e = tid; e < E; e += THREADS) {
+        if (!p.is_final) {
+            const uint32_t v = e & (V - 1), jb = e >> c;
+            const size_t go = ((size_t)a_fix << (s + lo_bits)) | ((size_t)jb << lo_bits) | (lo_base | v);
+            gstore(dst + go, lds_load(sh_lo, sh_hi, e));
+        } else {
+            const uint32_t vv = e & (V - 1), kp = e >> c;
+            Fr val = lds_load(sh_lo, sh_hi, brev(kp, s) * V + brev(vv, c));
+            const size_t go = ((size_t)kp << j0) | ((size_t)brev(a_fix, j0 - c) << c) | vv;
+            if (p.out_table) val = val * gload(p.out_table + ((size_t)blockIdx.y << p.log_n) + go);
+            else if (p.do_scale) val = val * p.scale;
+            gstore(dst + go, val);
+        }
+    }
+}
+
+// one thread per table entry (see ntt_build_coset_table)
+__global__ void ntt_dit_table_kernel(Fr c, Fr w, Fr g, uint32_t log_n, Fr* out) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e + 1 >= ((size_t)1 << log_n)) {
+        if (e + 1 == ((size_t)1 << log_n)) gstore(out + e, Fr::zero());   // the table's unused last element
+        return;
+    }
+    const uint32_t j = 63 - __clzll((unsigned long long)(e + 1));
+    const size_t k = e + 1 - ((size_t)1 << j);
+    Fr acc = c, sq = w;
+    for (size_t x = k; x; x >>= 1) {
+        if (x & 1) acc = acc * sq;
+        sq = Fr::sqr(sq);
+    }
+    for (uint32_t i = j + 1; i < log_n; i++) acc = Fr::sqr(acc);
+    if (e == 0) acc = acc * g;
+    gstore(out + e, acc);
 }
 
 // ------------------------------------------------------------------ the tile in 29-bit lazy arithmetic (SHP_NTT29=1)
@@ -474,6 +630,22 @@ __global__ void ntt_pass_table_kernel(Fr base, Fr first, uint32_t s, uint32_t lo
     }
 }
 
+// SHP_NTT_DIT=0 (read once per process) restores the transposing passes of ntt_pass_kernel for every transform
+static bool ntt_dit_mode() {
+    static const bool on = !(getenv("SHP_NTT_DIT") && atoi(getenv("SHP_NTT_DIT")) == 0) && !ntt29_mode();
+    return on;
+}
+bool ntt_dit_enabled() { return ntt_dit_mode(); }
+
+void ntt_build_coset_table(shp_ctx* ctx, uint32_t log_n, const Fr& c, const Fr& g, bool inverse, Fr* out, hipStream_t st) {
+    (void)ctx;
+    SHP_REQUIRE(log_n >= 1 && log_n <= 27 && out, SHP_ERR_INVALID_ARG, "ntt: coset table arguments");
+    const Fr w = inverse ? Fr::inv(fr_root_of_unity(log_n)) : fr_root_of_unity(log_n);
+    const size_t count = (size_t)1 << log_n;
+    hipLaunchKernelGGL(ntt_dit_table_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, st, c, w, g, log_n, out);
+    SHP_HIP(hipGetLastError());
+}
+
 // the pass structure of a transform: digits (stages per pass) and the tile size they are cut for
 static int ntt_digits(uint32_t log_n, uint32_t digits[3], uint32_t& tile_log) {
     tile_log = log_n <= 2 * NTT_TILE_SMALL ? NTT_TILE_SMALL : NTT_TILE_LARGE;
@@ -565,6 +737,13 @@ const NttTables& ntt_tables_for(shp_ctx* ctx, uint32_t log_n) {
         SHP_HIP(hipGetLastError());
         SHP_HIP(hipStreamSynchronize(ctx->stream));
     }
+    if (ntt_dit_mode() && log_n <= full_log) {
+        for (int d = 0; d < 2; d++) {
+            SHP_HIP(hipMalloc(&t.dit[d], sizeof(Fr) << log_n));
+            ntt_build_coset_table(ctx, log_n, Fr::one(), Fr::one(), d == 1, t.dit[d], ctx->stream);
+        }
+        SHP_HIP(hipStreamSynchronize(ctx->stream));
+    }
     t.n_inv = Fr::inv(Fr::from_u64(1ull << log_n));
     return ctx->ntt_tables.emplace(log_n, t).first->second;
 }
@@ -586,6 +765,45 @@ static void ntt_launch_with(shp_ctx* ctx, const NttTables& T, uint32_t tw_shift,
     }
     const uint32_t in_len = o.in_len ? o.in_len : (uint32_t)N;
     const size_t in_stride = o.in_stride ? o.in_stride : (o.in_len ? o.in_len : N);
+
+    // decimation in time with every factor in the butterflies: whole-length inputs without the zeta patterns, tables of
+    // this very domain (not the strided master tables of the allocation-free entry point)
+    const bool coset = o.twist != nullptr;
+    if (ntt_dit_mode() && tw_shift == 0 && T.dit[dir] && in_len == N && !o.pre_pattern && !o.post_pattern &&
+        (!coset || (o.coset_tw && o.twist_count))) {
+        uint32_t done = 0;
+        for (int pass = 0; pass < P; pass++) {
+            PassParams p = {};
+            p.log_n = log_n;
+            p.s = digits[pass];
+            p.j0 = done;
+            p.is_first = pass == 0;
+            p.is_final = pass == P - 1;
+            p.lo_bits = log_n - done - p.s;
+            const uint32_t cmax = tile_log - p.s;
+            p.c = p.is_final ? std::min(cmax, done) : std::min(cmax, p.lo_bits);
+            p.do_scale = o.inverse ? 1 : 0;
+            p.scale = T.n_inv;
+            p.out_table = p.is_final ? o.out_table : nullptr;
+            p.dit_tw = coset ? o.coset_tw : T.dit[dir];
+            p.dit_cosets = coset ? o.twist_count : 1;
+            p.dit_plain = coset ? 0 : 1;
+            p.dit_scaled = coset && o.coset_scaled ? (o.coset_g == Fr::from_u64(32) ? 2 : 1) : 0;
+            p.dit_g = o.coset_g;
+            if (p.is_first) { p.src = d_in; p.src_stride = in_stride; }
+            else { p.src = tmp; p.src_stride = N; }
+            if (p.is_final) { p.dst = d_out; p.dst_stride = N; }
+            else { p.dst = tmp; p.dst_stride = N; }
+            const uint32_t tiles = (uint32_t)(N >> (p.s + p.c));
+            if (tile_log == NTT_TILE_SMALL)
+                hipLaunchKernelGGL((ntt_dit_pass_kernel<256, NTT_TILE_SMALL>), dim3(tiles, batch), dim3(256), 0, st, p);
+            else
+                hipLaunchKernelGGL((ntt_dit_pass_kernel<512, NTT_TILE_LARGE>), dim3(tiles, batch), dim3(512), 0, st, p);
+            SHP_HIP(hipGetLastError());
+            done += p.s;
+        }
+        return;
+    }
 
     uint32_t consumed = 0;
     for (int pass = 0; pass < P; pass++) {

@@ -85,6 +85,8 @@ struct shp_pk {
     // matrix on the nodes c_j^n turn the per-coset interpolants back into the quotient pieces (coset_combine_kernel).
     uint32_t nc = 0, nq = 0;
     Fr *twist = nullptr, *vinv = nullptr, *cinv_n = nullptr;
+    Fr* coset_tw = nullptr;                  // [nc][n]: the coset transforms' butterfly twiddles (ntt_build_coset_table), with the twist in them
+    Fr coset_g;                              // the factor the twists carry (1, or 2^5 for a key with a generated quotient kernel)
     // device-resident constants
     Fr *fixed_vals = nullptr, *fixed_polys = nullptr, *fixed_cos = nullptr;
     Fr *sigma_vals = nullptr, *sigma_polys = nullptr, *sigma_cos = nullptr;
@@ -292,6 +294,11 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     pk->omegas = pk->dupload(om);
     pk->x_ext = pk->dupload(xe);
     pk->twist = pk->dupload(tw);
+    pk->coset_g = radix_shift;
+    if (ntt_dit_enabled()) {
+        pk->coset_tw = pk->dalloc<Fr>((size_t)nq);
+        for (uint32_t j = 0; j < nc; j++) ntt_build_coset_table(ctx, k, cj[j], radix_shift, false, pk->coset_tw + (size_t)j * n, st);
+    }
     {
         const Fr n_inv = Fr::inv(Fr::from_u64(n)) * ntt_out_table_factor();
         for (Fr& v : ci) v = v * n_inv;
@@ -324,6 +331,7 @@ static void keygen_impl(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan_bytes, s
     NttOpts ext;                                   // coefficients -> values on the nc cosets, [poly][coset][n]
     ext.twist = pk->twist;
     ext.twist_count = nc;
+    ext.coset_tw = pk->coset_tw; ext.coset_g = pk->coset_g; ext.coset_scaled = pk->quot_fn != nullptr;
     ntt_launch(ctx, pk->fixed_vals, pk->fixed_polys, k, F, inv, st, tmp);
     ntt_launch(ctx, pk->fixed_polys, pk->fixed_cos, k, F * nc, ext, st, tmp);
     ntt_launch(ctx, pk->sigma_vals, pk->sigma_polys, k, PC, inv, st, tmp);
@@ -1377,6 +1385,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     ntt_inv.inverse = true;
     NttOpts ntt_ext;                                     // values on the nc cosets of the quotient domain
     ntt_ext.twist = pk->twist; ntt_ext.twist_count = pk->nc;
+    ntt_ext.coset_tw = pk->coset_tw; ntt_ext.coset_g = pk->coset_g; ntt_ext.coset_scaled = pk->quot_fn != nullptr;
     uint32_t inv_done = 0, ext_done = 0;                 // columns [0, inv_done) have coefficients, [0, ext_done) cosets
     bool transforms_ahead = false;                       // ... the leading ones of them on the second stream (ev_tr)
     auto inv_upto = [&](uint32_t c) {
