@@ -264,6 +264,17 @@ struct alignas(16) Fp {
         return r;
 #endif
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The same product without its last conditional subtraction: below 2p whenever a b < p R (one operand below p, the
+    // other any 256-bit value below 4p).  For code that keeps values lazily in [0, 4p) -- 4p < 2^256 -- such as the
+    // butterflies of ntt_dit_pass_kernel.
+    static __device__ __forceinline__ Fp mul_lazy(const Fp& a, const Fp& b) {
+#include "field_mul_gfx950.inc"
+        return r;
+    }
+#else
+    static __device__ Fp mul_lazy(const Fp& a, const Fp& b);      // device code only (declared for the host pass)
+#endif
 #if !defined(__HIP_DEVICE_COMPILE__)
     // Host arithmetic on 4 x u64 limbs (the driver's witness program, transcript and point normalisation run on it: a
     // lone proof waits for three dependent Poseidon2 permutations of ~900 products each before its first kernel).  On a

@@ -206,6 +206,71 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
 // twiddles are the plain ones times c^(2^(log_n-1-j)) -- a table per coset (ntt_build_coset_table) instead of a product
 // per input coefficient.  Per element of a 2^13 coset transform: 6.5 products (7 with a scale factor on the outputs,
 // which takes a second product in the first stage) against 3.5 + 3 in the butterflies + 1 twist + 1 between the passes.
+// ---- lazy values for the butterflies: anything in [0, 4p) stands for its residue (4p < 2^256)
+// v - 2p where that is not negative: [0, 4p) -> [0, 2p)
+__device__ __forceinline__ constexpr uint32_t fr_2p(int i) {
+    return (FrParams::p(i) << 1) | (i ? FrParams::p(i - 1) >> 31 : 0);
+}
+__device__ __forceinline__ void fr_reduce_2p(Fr& v) {
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, keep;
+    asm("v_subrev_co_u32 %0, vcc, %17, %9\n\t"
+        "v_subbrev_co_u32 %1, vcc, %18, %10, vcc\n\t"
+        "v_subbrev_co_u32 %2, vcc, %19, %11, vcc\n\t"
+        "v_subbrev_co_u32 %3, vcc, %20, %12, vcc\n\t"
+        "v_subbrev_co_u32 %4, vcc, %21, %13, vcc\n\t"
+        "v_subbrev_co_u32 %5, vcc, %22, %14, vcc\n\t"
+        "v_subbrev_co_u32 %6, vcc, %23, %15, vcc\n\t"
+        "v_subbrev_co_u32 %7, vcc, %24, %16, vcc\n\t"
+        "v_cndmask_b32 %8, 0, -1, vcc"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(keep)
+        : "v"(v.l[0]), "v"(v.l[1]), "v"(v.l[2]), "v"(v.l[3]), "v"(v.l[4]), "v"(v.l[5]), "v"(v.l[6]), "v"(v.l[7]),
+          "v"(fr_2p(0)), "v"(fr_2p(1)), "v"(fr_2p(2)), "v"(fr_2p(3)), "v"(fr_2p(4)), "v"(fr_2p(5)), "v"(fr_2p(6)), "v"(fr_2p(7))
+        : "vcc");
+    v.l[0] = keep ? v.l[0] : t0; v.l[1] = keep ? v.l[1] : t1; v.l[2] = keep ? v.l[2] : t2; v.l[3] = keep ? v.l[3] : t3;
+    v.l[4] = keep ? v.l[4] : t4; v.l[5] = keep ? v.l[5] : t5; v.l[6] = keep ? v.l[6] : t6; v.l[7] = keep ? v.l[7] : t7;
+}
+// a + b as 256-bit integers (both below 2p: the sum is below 4p)
+__device__ __forceinline__ Fr fr_add_raw(const Fr& a, const Fr& b) {
+    Fr r = a;
+    asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %12, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %15, vcc"
+        : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7])
+        : "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+        : "vcc");
+    return r;
+}
+// a - b + 2p (both below 2p: the result is positive and below 4p; the wrap of the first chain is undone by the second)
+__device__ __forceinline__ Fr fr_sub_2p(const Fr& a, const Fr& b) {
+    Fr r = a;
+    asm("v_sub_co_u32 %0, vcc, %0, %8\n\t"
+        "v_subb_co_u32 %1, vcc, %1, %9, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %2, %10, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %3, %11, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %4, %12, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %5, %13, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %6, %14, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %7, %15, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %0, %16\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %17, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %18, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %19, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %20, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %5, %21, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %22, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %23, vcc"
+        : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7])
+        : "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]),
+          "v"(fr_2p(0)), "v"(fr_2p(1)), "v"(fr_2p(2)), "v"(fr_2p(3)), "v"(fr_2p(4)), "v"(fr_2p(5)), "v"(fr_2p(6)), "v"(fr_2p(7))
+        : "vcc");
+    return r;
+}
+
 // 32 x mod p without a product: x < p < 2^254 shifted up five bits, minus q p for q = (its top 32 bits) / (the modulus's top
 // 27 bits + 1) -- never above floor(32 x / p) and at most one below it -- leaves less than 2 p
 __device__ __forceinline__ Fr fr_times32(const Fr& x) {
@@ -296,12 +361,17 @@ __global__ __launch_bounds__(THREADS) void ntt_dit_pass_kernel(PassParams p) {
             const uint32_t grp = jbb >> t, pos = jbb & (half - 1);
             const uint32_t jA = (grp << (t + 1)) | pos;
             const uint32_t i0 = jA * V + v_t, i1 = (jA + half) * V + v_t;
+            // values are lazy, in [0, 4p): x comes down to [0, 2p), the product leaves y there without its last
+            // subtraction, the sum and the difference (+ 2p) are below 4p again -- one conditional subtraction a
+            // butterfly instead of three.  (The transform's inputs are below p, which the scaling of stage 0 relies on.)
             Fr x = lds_load(sh_lo, sh_hi, i0);
             Fr y = lds_load(sh_lo, sh_hi, i1);
-            if (k || !p.dit_plain) y = y * w;
+            if (k || !p.dit_plain) y = Fr::mul_lazy(y, w);
+            else fr_reduce_2p(y);
             if (p.dit_scaled && j == 0) x = p.dit_scaled == 2 ? fr_times32(x) : x * p.dit_g;
-            lds_store(sh_lo, sh_hi, i0, x + y);
-            lds_store(sh_lo, sh_hi, i1, x - y);
+            else fr_reduce_2p(x);
+            lds_store(sh_lo, sh_hi, i0, fr_add_raw(x, y));
+            lds_store(sh_lo, sh_hi, i1, fr_sub_2p(x, y));
         }
         __syncthreads();
     }
@@ -316,8 +386,10 @@ __global__ __launch_bounds__(THREADS) void ntt_dit_pass_kernel(PassParams p) {
             const uint32_t vv = e & (V - 1), kp = e >> c;
             Fr val = lds_load(sh_lo, sh_hi, brev(kp, s) * V + brev(vv, c));
             const size_t go = ((size_t)kp << j0) | ((size_t)brev(a_fix, j0 - c) << c) | vv;
+            // (a product takes the lazy value as it is and returns it reduced)
             if (p.out_table) val = val * gload(p.out_table + ((size_t)blockIdx.y << p.log_n) + go);
             else if (p.do_scale) val = val * p.scale;
+            else { fr_reduce_2p(val); val.reduce_once(); }
             gstore(dst + go, val);
         }
     }
