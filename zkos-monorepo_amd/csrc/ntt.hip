@@ -231,41 +231,43 @@ __device__ __forceinline__ void fr_reduce_2p(Fr& v) {
 }
 // a + b as 256-bit integers (both below 2p: the sum is below 4p)
 __device__ __forceinline__ Fr fr_add_raw(const Fr& a, const Fr& b) {
-    Fr r = a;
-    asm("v_add_co_u32 %0, vcc, %0, %8\n\t"
-        "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
-        "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
-        "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
-        "v_addc_co_u32 %4, vcc, %4, %12, vcc\n\t"
-        "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
-        "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
-        "v_addc_co_u32 %7, vcc, %7, %15, vcc"
-        : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7])
-        : "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
+    Fr r;
+    asm("v_add_co_u32 %0, vcc, %8, %16\n\t"
+        "v_addc_co_u32 %1, vcc, %9, %17, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %10, %18, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %11, %19, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %12, %20, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %13, %21, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %14, %22, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %15, %23, vcc"
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7])
+        : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+          "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7])
         : "vcc");
     return r;
 }
 // a - b + 2p (both below 2p: the result is positive and below 4p; the wrap of the first chain is undone by the second)
 __device__ __forceinline__ Fr fr_sub_2p(const Fr& a, const Fr& b) {
-    Fr r = a;
-    asm("v_sub_co_u32 %0, vcc, %0, %8\n\t"
-        "v_subb_co_u32 %1, vcc, %1, %9, vcc\n\t"
-        "v_subb_co_u32 %2, vcc, %2, %10, vcc\n\t"
-        "v_subb_co_u32 %3, vcc, %3, %11, vcc\n\t"
-        "v_subb_co_u32 %4, vcc, %4, %12, vcc\n\t"
-        "v_subb_co_u32 %5, vcc, %5, %13, vcc\n\t"
-        "v_subb_co_u32 %6, vcc, %6, %14, vcc\n\t"
-        "v_subb_co_u32 %7, vcc, %7, %15, vcc\n\t"
-        "v_add_co_u32 %0, vcc, %0, %16\n\t"
-        "v_addc_co_u32 %1, vcc, %1, %17, vcc\n\t"
-        "v_addc_co_u32 %2, vcc, %2, %18, vcc\n\t"
-        "v_addc_co_u32 %3, vcc, %3, %19, vcc\n\t"
-        "v_addc_co_u32 %4, vcc, %4, %20, vcc\n\t"
-        "v_addc_co_u32 %5, vcc, %5, %21, vcc\n\t"
-        "v_addc_co_u32 %6, vcc, %6, %22, vcc\n\t"
-        "v_addc_co_u32 %7, vcc, %7, %23, vcc"
-        : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7])
-        : "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]),
+    Fr r;
+    asm("v_sub_co_u32 %0, vcc, %8, %16\n\t"
+        "v_subb_co_u32 %1, vcc, %9, %17, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %10, %18, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %11, %19, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %12, %20, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %13, %21, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %14, %22, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %15, %23, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %0, %24\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %25, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %26, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %27, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %28, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %5, %29, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %30, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %31, vcc"
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7])
+        : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+          "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]),
           "v"(fr_2p(0)), "v"(fr_2p(1)), "v"(fr_2p(2)), "v"(fr_2p(3)), "v"(fr_2p(4)), "v"(fr_2p(5)), "v"(fr_2p(6)), "v"(fr_2p(7))
         : "vcc");
     return r;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(THREADS) void ntt_dit_pass_kernel(PassParams p) {
     auto brev = [](uint32_t x, uint32_t bits) -> uint32_t { return bits ? __brev(x) >> (32 - bits) : 0; };
 
     // ---- this thread's butterflies: one per stage (a tile has at most twice as many elements as the workgroup threads), in
-    // column v_t; the twiddle of stage jj sits at tw_index(jj) and is requested one stage ahead -- the first one before
+    // column v_t; the twiddle of stage jj is entry 2^(j0+jj) - 1 + tw_k(jj) and is requested a stage ahead -- the first one before
     // the tile is loaded -- so that a table entry that comes from the L2 or beyond arrives behind a barrier, not in front
     // of the product
     const bool active = tid < (E >> 1);
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(THREADS) void ntt_dit_pass_kernel(PassParams p) {
     const uint32_t a_t = p.is_final ? ((v_t << (j0 - c)) | a_fix) : a_fix;
     const uint32_t ra_t = brev(a_t, j0);
     auto tw_k = [&](uint32_t jj) -> uint32_t { return (brev(jbb >> (s - 1 - jj), jj) << j0) | ra_t; };
-    Fr w_next = Fr::zero();
-    if (active && s) w_next = gload(tw + (((size_t)1 << j0) - 1 + tw_k(0)));
+    Fr w = Fr::zero();
+    if (active && s) w = gload(tw + (((size_t)1 << j0) - 1 + tw_k(0)));
 
     // ---- load HBM -> LDS, [element of the pass][column]
     for (uint32_t e = tid; e < E; e += THREADS) {
@@ -347,29 +349,33 @@ __global__ __launch_bounds__(THREADS) void ntt_dit_pass_kernel(PassParams p) {
             gi = ((size_t)a << s) | jb;
             li = jb * V + v;
         }
-        lds_store(sh_lo, sh_hi, li, gload(src + gi));
+        Fr val = gload(src + gi);
+        // a factor on every output is a factor on both operands of the very first stage: its second operand finds it in
+        // the twiddle table's first entry, its first operand -- the half of the inputs whose top index bit is clear --
+        // takes it here
+        if (p.dit_scaled && p.is_first && (li >> c) < (L >> 1)) val = p.dit_scaled == 2 ? fr_times32(val) : val * p.dit_g;
+        lds_store(sh_lo, sh_hi, li, val);
     }
     __syncthreads();
 
     // ---- s stages, one butterfly per thread and stage
     for (uint32_t jj = 0; jj < s; jj++) {
         const uint32_t t = s - 1 - jj, half = 1u << t, j = j0 + jj;
-        const Fr w = w_next;
-        const uint32_t k = tw_k(jj);
-        if (active && jj + 1 < s) w_next = gload(tw + (((size_t)1 << (j + 1)) - 1 + tw_k(jj + 1)));
         if (active) {
+            const uint32_t k = tw_k(jj);
             const uint32_t grp = jbb >> t, pos = jbb & (half - 1);
             const uint32_t jA = (grp << (t + 1)) | pos;
             const uint32_t i0 = jA * V + v_t, i1 = (jA + half) * V + v_t;
             // values are lazy, in [0, 4p): x comes down to [0, 2p), the product leaves y there without its last
             // subtraction, the sum and the difference (+ 2p) are below 4p again -- one conditional subtraction a
-            // butterfly instead of three.  (The transform's inputs are below p, which the scaling of stage 0 relies on.)
-            Fr x = lds_load(sh_lo, sh_hi, i0);
+            // butterfly instead of three
             Fr y = lds_load(sh_lo, sh_hi, i1);
             if (k || !p.dit_plain) y = Fr::mul_lazy(y, w);
             else fr_reduce_2p(y);
-            if (p.dit_scaled && j == 0) x = p.dit_scaled == 2 ? fr_times32(x) : x * p.dit_g;
-            else fr_reduce_2p(x);
+            // the next stage's twiddle, into the registers the product has just finished with
+            if (jj + 1 < s) w = gload(tw + (((size_t)1 << (j + 1)) - 1 + tw_k(jj + 1)));
+            Fr x = lds_load(sh_lo, sh_hi, i0);
+            fr_reduce_2p(x);
             lds_store(sh_lo, sh_hi, i0, fr_add_raw(x, y));
             lds_store(sh_lo, sh_hi, i1, fr_sub_2p(x, y));
         }
