@@ -272,8 +272,8 @@ struct alignas(16) Fp {
 #include "field_mul_gfx950.inc"
         return r;
     }
-#else
-    static __device__ Fp mul_lazy(const Fp& a, const Fp& b);      // device code only (declared for the host pass)
+#elif defined(__HIPCC__)
+    static __device__ Fp mul_lazy(const Fp& a, const Fp& b);      // device code only (declared for hipcc's host pass)
 #endif
 #if !defined(__HIP_DEVICE_COMPILE__)
     // Host arithmetic on 4 x u64 limbs (the driver's witness program, transcript and point normalisation run on it: a
