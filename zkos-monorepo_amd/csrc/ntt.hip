@@ -205,8 +205,12 @@ __global__ __launch_bounds__(THREADS) void ntt_pass_kernel(PassParams p) {
 // all 2^log_n - 1 of them, a tile of the final pass reads the 2^s - 1 per column it needs, neighbouring columns
 // neighbouring entries).  A coset c H costs nothing either: f(c w^k) = f_e(c^2 w^2k) + c w^k f_o(c^2 w^2k), so stage j's
 // twiddles are the plain ones times c^(2^(log_n-1-j)) -- a table per coset (ntt_build_coset_table) instead of a product
-// per input coefficient.  Per element of a 2^13 coset transform: 6.5 products (7 with a scale factor on the outputs,
-// which takes a second product in the first stage) against 3.5 + 3 in the butterflies + 1 twist + 1 between the passes.
+// per input coefficient.  The number of products is the classical one either way (ntt_pass_kernel skips its trivial
+// twiddles: 2.5 + 2 in the butterflies + 1 between the passes + 1 twist per element of a 2^13 coset transform, 6.5 here,
+// where no twiddle of a coset is trivial); what goes is the twist's and the inter-pass factor's table loads and index
+// arithmetic, and -- below -- two of a butterfly's three conditional subtractions.  A factor on every output (dit_g) is
+// a factor on both operands of the first stage: table entry 0 carries it for the second, the first takes it at the tile
+// load, by shifts when it is 2^5.
 template <int THREADS, int TILE_LOG>
 __global__ __launch_bounds__(THREADS) void ntt_dit_pass_kernel(PassParams p) {
     __shared__ uint4 sh_lo[1 << TILE_LOG];
