@@ -2493,9 +2493,11 @@ int32_t shp_prover_witness_threads(shp_prover* p, uint32_t threads) {
 int32_t shp_prover_mode(shp_prover* p, uint32_t mode) {
     return guarded([&] {
         SHP_REQUIRE(p && mode <= 1, SHP_ERR_INVALID_ARG, "prover_mode: null prover or unknown mode");
-        // waves an MSM launch of a throughput lane should have before its lanes take more windows each (measured at
-        // 16 lanes: 256 -> 1260, 384 -> 1277, 512 -> 1290, 640 -> 1286, 768 -> 1255, 1024 -> 1233 proofs/s)
-        static const uint64_t tp_waves = getenv("SHP_TP_MIN_WAVES") ? (uint64_t)atol(getenv("SHP_TP_MIN_WAVES")) : 512;
+        // waves an MSM launch of a throughput lane should have before its lanes take more windows each: fewer waves are
+        // fewer partial sums for the reduction trees (a fifth of the kernel's instructions at 512), too few leave the
+        // launch to too few CUs.  Measured at 48 lanes, alternated on one box: 128 -> 2498, 256 -> 2520, 384 -> 2506,
+        // 512 -> 2490 proofs/s (at 16 lanes and the trees of an earlier build the optimum was 512)
+        static const uint64_t tp_waves = getenv("SHP_TP_MIN_WAVES") ? (uint64_t)atol(getenv("SHP_TP_MIN_WAVES")) : 256;
         p->msm_ws.min_waves = mode ? tp_waves : 0;
         p->throughput = mode != 0;
         p->msm_ws.poll_results = !mode && poll_results_enabled();   // pool lanes sleep in their stream waits instead
