@@ -114,7 +114,9 @@ int32_t shp_encode_calldata(const uint8_t* proof, size_t proof_len, const uint8_
 /* ---- NTT over Fr  (halo2 EvaluationDomain: best_fft / lagrange_to_coeff / coeff_to_extended;
  *      conventions pinned by resources/ppot_0080_11_raw and Halo2Verifier.sol:475) ------ */
 /* `batch` polynomials of 2^log_n elements each, contiguous, in place, natural order in and out.
- * inverse != 0: omega^{-1} and the 1/n scaling (lagrange_to_coeff). */
+ * inverse != 0: omega^{-1} and the 1/n scaling (lagrange_to_coeff).  Elements are reduced Montgomery
+ * residues (below the modulus), as everywhere at this boundary: the butterflies keep their values lazily
+ * in [0, 4r) and rely on inputs below r. */
 int32_t shp_ntt_fr(shp_ctx* ctx, void* d_data, uint32_t log_n, uint32_t batch, int32_t inverse, void* stream);
 /* shp_ntt_fr for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc.  No counterpart in the reference.  Same arguments and results as shp_ntt_fr; the
