@@ -280,7 +280,12 @@ int32_t shp_prover_destroy(shp_prover* p);
  *   seed           32 bytes keying the ChaCha20 blinding stream (the reference's `rng`); Fr draw i is
  *                  from_u512(ChaCha20(seed, block i)), consumed in the order given at shp_prove_with_randomness
  *   proof_out      caller buffer (capacity proof_cap, >= shp_pk_info proof_len); *proof_len is set
- *   instances_le32 optional: the public inputs (serialize_public_input), 32-byte LE canonical each */
+ *   instances_le32 optional: the public inputs (serialize_public_input), 32-byte LE canonical each
+ * Failures of the proof itself, as create_proof's: SHP_ERR_UNSATISFIED when a lookup input is not in its table;
+ * SHP_ERR_INVALID_ARG ("... point at infinity ...") when a commitment is the identity -- halo2's transcripts refuse to
+ * write it and the reference's verifier rejects (0, 0) as a proof point
+ * (/root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:89-99), so such a circuit and witness have no
+ * proof.  The lane stays usable after either. */
 int32_t shp_prove(shp_prover* p, const uint8_t* witness_le32, size_t n_inputs, const uint8_t seed[32],
                   uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* instances_le32,
                   size_t instances_cap);

@@ -277,6 +277,10 @@ def mock_check(plan: Plan, advice, instances, challenges=()):
 
 
 # ------------------------------------------------------------------------------ transcript
+class PointAtInfinity(ValueError):
+    """create_proof's failure when a commitment is the identity (see Transcript.write_point)"""
+
+
 class Transcript:
     """EVM Keccak transcript: Halo2Verifier.sol:105-124, 247-307"""
 
@@ -296,6 +300,12 @@ class Transcript:
 
     def write_point(self, pt):
         b = g1_be64(pt)
+        # halo2's transcripts refuse the identity ("cannot write points at infinity to the transcript", an
+        # Error::Transcript out of create_proof), and the reference's verifier refuses (0, 0) as a proof point
+        # (/root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:89-99, read_ec_point: y^2 = x^3 + 3 fails): a circuit whose
+        # commitment is the identity -- a quotient piece that is identically zero, say -- has no proof
+        if b == bytes(64):
+            raise PointAtInfinity("a commitment is the point at infinity: the transcript refuses it")
         self.buf += b
         self.proof += b
 

@@ -110,3 +110,22 @@ def test_new_account_shaped_plan(oracle):
     big = list(wit); big[2] = 1 << 40
     g2, i2 = PL.synthesize(plan, big)
     assert PL.mock_check(plan, g2, i2) != []
+
+
+def test_commitment_at_infinity_is_refused(oracle):
+    """A circuit one of whose commitments is the identity has no proof: halo2's transcripts refuse to write the point at
+    infinity (create_proof fails with Error::Transcript) and the reference's verifier rejects (0, 0) as a proof point
+    (/root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:89-99).  Plan 1070 of the fuzz generator is such a
+    circuit -- no permutation, no lookup, gates of degree 2 under halo2's degree floor of 3: the second quotient piece is
+    identically zero -- and the oracle's prover refuses it the same way (the HIP prover: tests/test_gpu_fuzz_plans.py)."""
+    from oracle import plonk as PL
+    from test_gpu_fuzz_plans import random_plan, TAU
+    plan_bytes, k, values = random_plan(1070)
+    plan = PL.Plan(plan_bytes)
+    assert plan.degree == 3 and not plan.lookups and not plan.perm_cols
+    osrs = oracle.srs_synthetic(k, TAU)
+    opk = PL.keygen(plan, osrs)
+    adv_grid, insts = PL.synthesize(plan, values)
+    assert PL.mock_check(plan, adv_grid, insts) == []
+    with pytest.raises(PL.PointAtInfinity):
+        PL.prove(opk, osrs, values, bytes(32))

@@ -1449,6 +1449,15 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     Fr* const instcol = grid + (size_t)A * n;           // rows past the instances stay zero (cleared at creation)
     uint32_t rows_now;                                  // leading rows of the advice columns that this proof may fill
     Transcript tr(pk->vk_digest);
+    // halo2's transcripts refuse the identity ("cannot write points at infinity to the transcript": create_proof fails with
+    // Error::Transcript) and the reference's verifier refuses (0, 0) as a proof point
+    // (/root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:89-99): a circuit one of whose commitments is the
+    // identity -- a quotient piece that is identically zero, say -- has no proof, and proving it is refused here as well
+    auto put_point = [&](const G1Affine& pt) {
+        SHP_REQUIRE(!(pt.x.is_zero() && pt.y.is_zero()), SHP_ERR_INVALID_ARG,
+                    "prove: a commitment is the point at infinity, which the transcript refuses (as halo2's does): this circuit and witness have no proof");
+        tr.write_point(pt.x, pt.y);
+    };
     std::vector<G1Affine> pts(std::max<uint32_t>({A + 2 * L + 1, S + L + 1, P.degree}));
     std::vector<Fr> chal(P.challenge_phase.size(), Fr::zero());
     ProgArgs pa;
@@ -1696,7 +1705,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
             jobs[n_jobs++] = MsmJob{srs->msm_gl, rand_lag, n, 1, MsmRows{n, 0, 0}, &rand_comm};
             commit_jobs(jobs, n_jobs);
         }
-        for (uint32_t c = 0; c < A; c++) tr.write_point(pts[c].x, pts[c].y);
+        for (uint32_t c = 0; c < A; c++) put_point(pts[c]);
     } else {
         // Several phases (halo2 create_proof's loop over the phases; the reference's verifier reads the proof this way,
         // /root/reference/crates/halo2-verifier/templates/Halo2Verifier.sol:267-282): per phase the witness with the challenges
@@ -1779,7 +1788,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
                 commit(srs->msm_gl, rand_lag, 1, &rand_comm);
             }
             for (const auto& run : runs)
-                for (uint32_t c = run.first; c < run.first + run.second; c++) tr.write_point(pts[c].x, pts[c].y);
+                for (uint32_t c = run.first; c < run.first + run.second; c++) put_point(pts[c]);
             for (size_t i = 0; i < chal.size(); i++)
                 if (P.challenge_phase[i] == ph) chal[i] = tr.squeeze();
         }
@@ -1804,12 +1813,12 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         }
         for (uint32_t l = 0; l < L; l++)
             SHP_REQUIRE(herr[l] == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
-        for (uint32_t i = 0; i < 2 * L; i++) tr.write_point(pts[i].x, pts[i].y);
+        for (uint32_t i = 0; i < 2 * L; i++) put_point(pts[i]);
     } else if (L) {
         if (lookups_ahead) msm_finish_jobs(pr->msm_ws_perm, pr->st2);
         for (uint32_t l = 0; l < L; l++)
             SHP_REQUIRE(early_err[l] == 0, SHP_ERR_UNSATISFIED, "prove: lookup input not contained in the table");
-        for (uint32_t i = 0; i < 2 * L; i++) tr.write_point(pts[A + i].x, pts[A + i].y);
+        for (uint32_t i = 0; i < 2 * L; i++) put_point(pts[A + i]);
     }
     pc.mark("lookup");
     // ---- P4
@@ -1872,8 +1881,8 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     } else {
         commit(srs->msm_gl, V(I_PZ), S + L, pts.data());
     }
-    for (uint32_t i = 0; i < S + L; i++) tr.write_point(pts[i].x, pts[i].y);
-    tr.write_point(rand_comm.x, rand_comm.y);
+    for (uint32_t i = 0; i < S + L; i++) put_point(pts[i]);
+    put_point(rand_comm);
     pc.mark("products_msm");
     // ---- P8
     const Fr y = tr.squeeze();
@@ -1967,7 +1976,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
     Fr* const hp_lag = pr->h;                            // the pieces' values on the domain (the interpolants are consumed)
     ntt_launch(ctx, hp, hp_lag, k, npieces, ntt_fwd, st, pr->ntt_tmp);
     commit(srs->msm_gl, hp_lag, npieces, pts.data());
-    for (uint32_t i = 0; i < npieces; i++) tr.write_point(pts[i].x, pts[i].y);
+    for (uint32_t i = 0; i < npieces; i++) put_point(pts[i]);
     pc.mark("quotient_msm");
     // ---- P11: evaluations
     const Fr x = tr.squeeze();
@@ -2125,7 +2134,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
                        zpow, n, pr->fsets);
     hipLaunchKernelGGL(shplonk_w_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, sa, n, pr->wvals);
     commit(srs->msm_gl, pr->wvals, 1, pts.data());
-    tr.write_point(pts[0].x, pts[0].y);
+    put_point(pts[0]);
     pc.mark("W");
     // ---- P13: W'
     const Fr mu = tr.squeeze();
@@ -2162,7 +2171,7 @@ static void prove_impl(shp_prover* pr, const ProveInput& in, std::vector<uint8_t
         pr->timers.end(st);
     }
     commit(srs->msm_gl, pr->wvals + n, 1, pts.data());
-    tr.write_point(pts[0].x, pts[0].y);
+    put_point(pts[0]);
     pc.mark("Wprime");
     SHP_HIP(hipGetLastError());
     pr->proofs_done++;
