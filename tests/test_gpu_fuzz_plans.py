@@ -187,10 +187,11 @@ def random_plan(seed, describe=False):
 
 # FUZZ_SEEDS=N widens the sweep (a soak run: 400 seeds take ~2 minutes on the GPU box)
 _FUZZ_SEEDS = int(__import__("os").environ.get("FUZZ_SEEDS", "48"))
+_FUZZ_FIRST = int(__import__("os").environ.get("FUZZ_FIRST", "1"))        # first seed of the sweep (a soak run's next slice)
 
 
 # (plan 1070 is the degenerate one -- a commitment at infinity, refused by oracle and library alike: always in the sweep)
-@pytest.mark.parametrize("seed", list(range(1, 1 + _FUZZ_SEEDS)) + ([1070] if _FUZZ_SEEDS < 1070 else []))
+@pytest.mark.parametrize("seed", list(range(_FUZZ_FIRST, _FUZZ_FIRST + _FUZZ_SEEDS)) + ([1070] if not _FUZZ_FIRST <= 1070 < _FUZZ_FIRST + _FUZZ_SEEDS else []))
 def test_random_plan_proof_bytes(shp, oracle, gpu_ctx, seed):
     from oracle import plonk as PL
     plan_bytes, k, values = random_plan(seed)
