@@ -208,7 +208,7 @@ int32_t shp_srs_commit(shp_srs* srs, int32_t basis, const void* d_polys, uint32_
  * outlive the key.  Fixed/permutation polynomials, their extended cosets and commitments are
  * computed on the GPU.
  * Capacity: the opening argument handles at most 8 SHPLONK rotation sets over at most 8 distinct rotations (the
- * reference's circuits use four sets over {0, 1, -1, last}); a plan beyond that is refused here with
+ * shipped withdraw-, deposit- and new-account-shaped plans have four sets over the rotations {0, 1, -1, last}); a plan beyond that is refused here with
  * SHP_ERR_INVALID_ARG ("keygen: too many rotation sets"), never later. */
 int32_t shp_keygen(shp_ctx* ctx, shp_srs* srs, const uint8_t* plan, size_t plan_len, shp_pk** out);
 /* shp_keygen for integrators that hold the halo2 VerifyingKey: `transcript_repr_le32` (32-byte little-endian canonical)

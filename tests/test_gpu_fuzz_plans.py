@@ -203,7 +203,7 @@ def test_random_plan_proof_bytes(shp, oracle, gpu_ctx, seed):
         pk = shp.ProvingKey(gpu_ctx, params, plan_bytes)
     except shp.ShpError as e:
         # the library's documented capacity (include/shielder_hip.h, shp_keygen): at most 8 SHPLONK rotation sets over at
-        # most 8 distinct rotations -- the reference's circuits use four.  About one generated plan in six thousand
+        # most 8 distinct rotations -- the shipped plans have four sets.  About one generated plan in six thousand
         # exceeds it (6432 has nine sets); the refusal must be that one, at keygen, and only for such a plan
         superset, sets = PL.rotation_sets(PL.build_queries(plan, None))
         assert e.code == shp.SHP_ERR_INVALID_ARG and "too many rotation sets" in str(e), str(e)
